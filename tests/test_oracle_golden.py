@@ -1,0 +1,217 @@
+"""The CPU oracle (oracle/osvos_ref.py) against fixtures produced by the reference itself
+(oracle/make_golden.py).  Runs on CPU; this is what pins parity."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import osvos_ref as O
+
+RTOL = 1e-5  # fp32 restatement vs the reference on the same torch build
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def check_digest(t, m, idx, smp, rtol=RTOL, scale=None):
+    f = t.detach().reshape(-1).double()
+    got = np.array([f.sum().item(), f.abs().sum().item(), (f * f).sum().item()])
+    ref_scale = max(abs(m[1]), 1e-30)
+    assert abs(got[0] - m[0]) <= rtol * ref_scale * 10
+    assert abs(got[1] - m[1]) <= rtol * ref_scale * 10
+    assert abs(got[2] - m[2]) <= rtol * max(m[2], 1e-30) * 10
+    s = t.detach().reshape(-1)[T(idx)].double().numpy()
+    tol = rtol * (np.abs(smp).max() + 1e-30) * 10 if scale is None else scale
+    np.testing.assert_allclose(s, smp, rtol=rtol * 10, atol=tol)
+
+
+def test_bilinear_kernel(golden):
+    k = golden("kat.npz")
+    for size in (3, 4, 5, 8, 16, 32):
+        np.testing.assert_array_equal(O.bilinear_kernel(size), k[f"filt_{size}"])
+    assert list(O.bilinear_kernel(4)[0]) == [.0625, .1875, .1875, .0625]
+    for size, total in ((4, 4), (8, 16), (16, 64), (32, 256)):
+        assert O.bilinear_kernel(size).sum() == total
+    for c, size in ((16, 4), (1, 8), (3, 16)):
+        np.testing.assert_array_equal(O.bilinear_deconv_weight(c, size).numpy(), k[f"surgery_{c}_{size}"])
+
+
+def test_center_crop(golden):
+    k = golden("kat.npz")
+    src = T(k["crop_src"])
+    for h, w in k["crop_cases"]:
+        np.testing.assert_array_equal(O.center_crop(src, int(h), int(w)).numpy(), k[f"crop_{h}_{w}"])
+    # the odd pixel comes off the bottom/right
+    assert O.crop_offsets(11, 8) == (1, 2)
+    assert O.crop_offsets(482, 480) == (1, 1)
+    assert O.crop_offsets(880, 854) == (13, 13)
+    assert O.crop_offsets(860, 854) == (3, 3)
+    assert O.crop_offsets(6, 1) == (2, 3)
+
+
+@pytest.mark.parametrize("tag", ["kat12", "allneg", "allpos", "extreme", "rand", "soft"])
+def test_cbce(golden, tag):
+    k = golden("kat.npz")
+    x, y = T(k[f"loss_{tag}_x"]), T(k[f"loss_{tag}_y"])
+    ls = O.cbce_loss(x, y, size_average=False)
+    la = O.cbce_loss(x, y, size_average=True)
+    np.testing.assert_allclose(ls.item(), k[f"loss_{tag}_sum"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(la.item(), k[f"loss_{tag}_avg"], rtol=2e-6, atol=1e-7)
+    g = O.cbce_loss_grad(x, y, size_average=False)
+    np.testing.assert_allclose(g.numpy(), k[f"loss_{tag}_grad"], rtol=1e-5, atol=1e-7)
+    xr = x.clone().requires_grad_(True)
+    (ga,) = torch.autograd.grad(O.cbce_loss(xr, y, size_average=False), xr)
+    np.testing.assert_allclose(ga.numpy(), k[f"loss_{tag}_grad"], rtol=1e-5, atol=1e-7)
+
+
+def test_cbce_known_values():
+    x = torch.linspace(-3, 3, 12).view(1, 1, 3, 4)
+    y = torch.tensor([0, 0, 1, 0, 0, 1, 1, 0, 0, 0, .5, .49]).view(1, 1, 3, 4)
+    assert abs(O.cbce_loss(x, y, False).item() - 5.221406936645508) < 1e-5
+    assert abs(O.cbce_loss(x, y, True).item() - 0.435117244720459) < 1e-6
+    assert abs(O.cbce_loss_grad(x, y, False).reshape(-1)[2].item() - (-0.58061135)) < 1e-6
+    assert O.cbce_loss(x, torch.zeros_like(x), False).item() == 0.0
+    xe = torch.tensor([-100., 100., 0.]).view(1, 1, 1, 3)
+    ye = torch.tensor([1., 0., 1.]).view(1, 1, 1, 3)
+    assert abs(O.cbce_loss(xe, ye, False).item() - 100.2310562) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
+def test_layer_stacks(golden, tag):
+    """pool(ceil) + conv3x3 + bias + relu stacks built by the reference's _make_layers_osvos."""
+    import torch.nn.functional as F
+    k = golden("stacks.npz")
+    cfg = [int(v) for v in k[f"{tag}_cfg"]]
+    x = T(k[f"{tag}_x"]).clone().requires_grad_(True)
+    params = []
+    h = x
+    pi = 0
+    for v in cfg:
+        if v < 0:
+            h = F.max_pool2d(h, 2, 2, ceil_mode=True)
+        else:
+            w = T(k[f"{tag}_p{pi}"]).clone().requires_grad_(True)
+            b = T(k[f"{tag}_p{pi + 1}"]).clone().requires_grad_(True)
+            pi += 2
+            params += [w, b]
+            h = F.relu(F.conv2d(h, w, b, padding=1))
+    np.testing.assert_allclose(h.detach().numpy(), k[f"{tag}_y"], rtol=1e-5, atol=1e-5)
+    grads = torch.autograd.grad(h, [x] + params, T(k[f"{tag}_gy"]))
+    np.testing.assert_allclose(grads[0].numpy(), k[f"{tag}_gx"], rtol=1e-4, atol=1e-4)
+    for i, g in enumerate(grads[1:]):
+        np.testing.assert_allclose(g.numpy(), k[f"{tag}_gp{i}"], rtol=1e-4, atol=1e-3)
+
+
+def test_state_dict_spec(golden):
+    k = golden("net.npz")
+    spec = O.state_dict_spec()
+    assert list(spec.keys()) == [str(s) for s in k["keys"]]
+    assert [str(tuple(v)) for v in spec.values()] == [str(s) for s in k["shapes"]]
+    assert len(spec) == 52
+    assert sum(int(np.prod(s)) for s in spec.values()) == 15267157
+    sd = O.make_state_dict(0, "reference")
+    for i in range(4):
+        np.testing.assert_array_equal(sd[f"upscale.{i}.weight"][3, 3].numpy(), k[f"init_upscale_{i}_diag"])
+        assert sd[f"upscale.{i}.weight"][3, 5].abs().max().item() == k[f"init_upscale_{i}_offdiag_absmax"] == 0
+        np.testing.assert_array_equal(sd[f"upscale_.{i}.weight"][0, 0].numpy(), k[f"init_upscale__{i}"])
+    assert abs(sd["stages.2.1.weight"].std().item() - float(k["init_conv_std"])) < 5e-5
+    assert float(k["init_bias_absmax"]) == 0.0 == sd["stages.2.1.bias"].abs().max().item()
+
+
+@pytest.mark.parametrize("tag", ["s", "r"])
+def test_full_network(golden, tag):
+    k = golden("net.npz")
+    n, h, w = (int(v) for v in k[f"{tag}_shape"])
+    sd = O.make_state_dict(int(k[f"{tag}_seed"]))
+    x, gt = O.synthetic_frame(n, h, w, seed=int(k[f"{tag}_frame_seed"]))
+    params = O.leaf_params(sd)
+    outs = O.forward(params, x)
+    assert len(outs) == 5
+    losses = []
+    for i, o in enumerate(outs):
+        ref = k[f"{tag}_out{i}"]
+        assert tuple(o.shape) == ref.shape == (n, 1, h, w)
+        np.testing.assert_allclose(o.detach().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+        li = O.cbce_loss(o, gt, size_average=False)
+        losses.append(li)
+        np.testing.assert_allclose(li.item(), float(k[f"{tag}_loss{i}"]), rtol=1e-5)
+    # online objective
+    names = list(params.keys())
+    g_on = torch.autograd.grad(losses[-1], list(params.values()), retain_graph=True, allow_unused=True)
+    nograd = set(str(s) for s in k[f"{tag}_on_nograd"])
+    assert nograd == {nm for nm, g in zip(names, g_on) if g is None}
+    assert nograd == {f"score_dsn.{i}.{p}" for i in range(4) for p in ("weight", "bias")} | {
+        f"upscale_.{i}.weight" for i in range(4)}
+    for nm, g in zip(names, g_on):
+        if g is not None:
+            check_digest(g, k[f"{tag}_on_g_{nm}_m"], k[f"{tag}_on_g_{nm}_i"], k[f"{tag}_on_g_{nm}_s"], rtol=1e-4)
+    g_off = torch.autograd.grad((1 - 60 / 240) * sum(losses[:-1]) + losses[-1], list(params.values()))
+    for nm, g in zip(names, g_off):
+        check_digest(g, k[f"{tag}_off_g_{nm}_m"], k[f"{tag}_off_g_{nm}_i"], k[f"{tag}_off_g_{nm}_s"], rtol=1e-4)
+
+
+def test_optimizer_groups(golden):
+    k = golden("loops.npz")
+    for mode in ("online", "offline"):
+        params = O.leaf_params(O.make_state_dict(5))
+        opt = O.make_sgd(params, mode)
+        names = {id(p): n for n, p in params.items()}
+        rows = []
+        for gi, grp in enumerate(opt.param_groups):
+            for p in grp["params"]:
+                rows.append(f"{gi}|{names[id(p)]}|{grp['lr']!r}|{grp['weight_decay']!r}|{grp['momentum']!r}")
+        assert rows == [str(s) for s in k[f"groups_{mode}"]]
+
+
+@pytest.mark.parametrize("tag,lr", [("lr1e-8", 1e-8), ("lr1e-6", 1e-6)])
+def test_online_loop(golden, tag, lr):
+    k = golden("loops.npz")
+    sd = O.make_state_dict(6)
+    f0 = O.synthetic_frame(1, 48, 86, seed=21)
+    f1 = O.synthetic_frame(1, 40, 70, seed=22)
+    losses, final = O.online_loop(sd, [f0[0], f1[0]], [f0[1], f1[1]], 10, 5, lr=lr)
+    np.testing.assert_allclose(losses, k[f"online_{tag}_loss"], rtol=2e-5)
+    for nm in sd:
+        d = final[nm].double() - sd[nm].double()
+        m = k[f"online_{tag}_delta_{nm}_m"]
+        check_digest(d, m, k[f"online_{tag}_delta_{nm}_i"], k[f"online_{tag}_delta_{nm}_s"], rtol=2e-3,
+                     scale=2e-3 * (np.abs(k[f"online_{tag}_delta_{nm}_s"]).max() + 1e-30) + 1e-12)
+    np.testing.assert_allclose(final["fuse.weight"].numpy(), k[f"online_{tag}_fuse_weight"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(final["stages.0.0.bias"].numpy(), k[f"online_{tag}_stage00_bias"], rtol=1e-6, atol=1e-9)
+    # frozen / unoptimised tensors do not move (src/util/network_provider.py:154-155, score_dsn absent)
+    for nm in sd:
+        if nm.startswith(("upscale", "score_dsn")):
+            assert torch.equal(final[nm], sd[nm])
+
+
+def test_offline_loop(golden):
+    k = golden("loops.npz")
+    sd = O.make_state_dict(8)
+    x, gt = O.synthetic_frame(2, 33, 47, seed=23)
+    trace, final = O.offline_loop(sd, [x], [gt], 4, epoch=60, n_epochs=240, avg_grad_every_n=2, lr=1e-6)
+    np.testing.assert_allclose(np.array(trace), k["offline_loss"], rtol=2e-5)
+    for nm in sd:
+        d = final[nm].double() - sd[nm].double()
+        check_digest(d, k[f"offline_delta_{nm}_m"], k[f"offline_delta_{nm}_i"], k[f"offline_delta_{nm}_s"],
+                     rtol=2e-3, scale=2e-3 * (np.abs(k[f"offline_delta_{nm}_s"]).max() + 1e-30) + 1e-12)
+
+
+def test_e2e_frame(golden):
+    """One 854x480 frame through the oracle vs the reference's stored logits/mask."""
+    k = golden("e2e_480x854.npz")
+    sd = O.make_state_dict(int(k["seed"]))
+    x, gt = O.synthetic_frame(1, 480, 854, seed=int(k["frame_seed"]))
+    with torch.no_grad():
+        outs = O.forward(sd, x)
+    fused = outs[-1][0, 0]
+    ref = T(k["logits_f16"]).float()
+    amax = float(k["logits_absmax"])
+    assert (fused - ref).abs().max().item() <= 2e-3 * amax  # fp16 storage resolution
+    ref_mask = T(np.unpackbits(k["mask_bits"])[: 480 * 854].reshape(480, 854)).bool()
+    mask = O.logits_to_mask(fused)
+    band = fused.abs() > 1e-4 * amax
+    assert torch.equal(mask[band], ref_mask[band])
+    assert abs(O.mask_iou(mask, ref_mask) - 1.0) <= 1e-3
+    np.testing.assert_allclose(O.cbce_loss(outs[-1], gt, False).item(), float(k["loss_fused_sum"]), rtol=1e-5)
+    for i in range(4):
+        check_digest(outs[i], k[f"side{i}_m"], k[f"side{i}_i"], k[f"side{i}_s"], rtol=1e-4)
