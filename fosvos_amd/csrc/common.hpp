@@ -1,0 +1,90 @@
+// Shared host/device helpers for libfosvos_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/fosvos_hip.h"
+
+namespace fosvos {
+
+// ------------------------------------------------------------------------------------------ errors
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+inline int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define FOSVOS_HIP_CHECK(expr)                                                                         \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return ::fosvos::fail(FOSVOS_E_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                                  __LINE__);                                                           \
+    } while (0)
+
+#define FOSVOS_REQUIRE(cond, code, ...)                    \
+    do {                                                   \
+        if (!(cond)) return ::fosvos::fail(code, __VA_ARGS__); \
+    } while (0)
+
+// Select the device for this call (backward runs on an autograd thread with its own current device).
+#define FOSVOS_ENTER(device) FOSVOS_HIP_CHECK(hipSetDevice(device))
+#define FOSVOS_LAUNCH_CHECK() FOSVOS_HIP_CHECK(hipGetLastError())
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
+
+// ------------------------------------------------------------------------------------------ bf16
+typedef uint16_t bf16_t;  // storage type
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even, NaN stays NaN
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4 &v, float (&f)[8]) {
+    f[0] = __uint_as_float(v.x << 16);
+    f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16);
+    f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16);
+    f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16);
+    f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint4 v;
+    v.x = pack2bf(f[0], f[1]);
+    v.y = pack2bf(f[2], f[3]);
+    v.z = pack2bf(f[4], f[5]);
+    v.w = pack2bf(f[6], f[7]);
+    return v;
+}
+
+// wave64 all-lanes sum
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace fosvos

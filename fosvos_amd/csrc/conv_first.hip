@@ -1,0 +1,215 @@
+// conv1_1: Conv2d(3 -> Co, 3x3, pad 1) + bias + ReLU straight from the fp32 NCHW frame, and its
+// weight/bias gradient (reference: stages[0][0..1], src/networks/osvos_vgg.py:92-93).
+//
+// K = 27 is far too small for MFMA to pay; both kernels are fp32 VALU and bandwidth-leaning:
+//   fwd   reads 12 B/pixel of frame, writes 2*Co B/pixel of bf16 NHWC activation
+//   wgrad reads 2*Co B/pixel of dy (+ the frame through the scalar cache), writes Co*28 floats/block
+// No dgrad: the image needs no gradient.
+#include "common.hpp"
+
+using namespace fosvos;
+
+namespace {
+constexpr int CO = 64;     // the only instantiation the model needs (checked at the entry point)
+constexpr int TW = 64;     // pixels per wave (one image-row segment)
+constexpr int ROWS = 4;    // waves per block = image rows per block
+constexpr int PX = 8;      // consecutive pixels per thread
+
+// ---------------------------------------------------------------------------------------- forward
+// Block = 4 waves = 4 image rows x 64 pixels.  Lane l of a wave owns pixels 8*(l/8)..+7 of the
+// segment and output channels 8*(l%8)..+7, so the 8 lanes of a pixel store one full 128-byte
+// NHWC pixel.  Weights live in LDS as [27][64] fp32 (each lane reads its 8 channels as 2 x 16 B:
+// the 8 channel groups cover one 256-byte bank row, conflict-free); the 6 x 66 input halo rows
+// per channel live in LDS too and are read as broadcasts within a pixel group.
+__global__ __launch_bounds__(256) void k_first_fwd(const float *__restrict__ frame, const float *__restrict__ w,
+                                                    const float *__restrict__ bias, uint16_t *__restrict__ y, int H,
+                                                    int W) {
+    __shared__ __attribute__((aligned(16))) float s_w[27][CO];
+    __shared__ __attribute__((aligned(16))) float s_in[3][ROWS + 2][TW + 8];  // x index 0 <-> image x0-4 (16-B aligned)
+    const int n = blockIdx.z;
+    const int y0 = blockIdx.y * ROWS;
+    const int x0 = blockIdx.x * TW;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 27 * CO; i += 256) {
+        const int co = i % CO, k = i / CO;  // k = ci*9 + tap
+        s_w[k][co] = w[co * 27 + k];
+    }
+    const int64_t plane = (int64_t)H * W;
+    for (int i = tid; i < 3 * (ROWS + 2) * (TW + 8); i += 256) {
+        const int xx = i % (TW + 8);
+        const int r = (i / (TW + 8)) % (ROWS + 2);
+        const int c = i / ((TW + 8) * (ROWS + 2));
+        const int gy = y0 + r - 1, gx = x0 + xx - 4;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = frame[((int64_t)n * 3 + c) * plane + (int64_t)gy * W + gx];
+        s_in[c][r][xx] = v;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int pg = lane >> 3, cg = lane & 7;
+    const int gy = y0 + wave;
+    if (gy >= H) return;
+    float acc[PX][8];
+    {
+        const float4 b0 = *reinterpret_cast<const float4 *>(bias + cg * 8);
+        const float4 b1 = *reinterpret_cast<const float4 *>(bias + cg * 8 + 4);
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            acc[p][0] = b0.x; acc[p][1] = b0.y; acc[p][2] = b0.z; acc[p][3] = b0.w;
+            acc[p][4] = b1.x; acc[p][5] = b1.y; acc[p][6] = b1.z; acc[p][7] = b1.w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            // inputs x = 8*pg-1 .. 8*pg+8 of halo row (wave + ky): LDS x index = 8*pg + 3 .. 8*pg + 12
+            float in[PX + 2];
+            const float *row = &s_in[c][wave + ky][pg * 8];
+            const float4 a = *reinterpret_cast<const float4 *>(row);       // idx 0..3
+            const float4 b = *reinterpret_cast<const float4 *>(row + 4);   // idx 4..7
+            const float4 d = *reinterpret_cast<const float4 *>(row + 8);   // idx 8..11
+            const float e = row[12];
+            in[0] = a.w; in[1] = b.x; in[2] = b.y; in[3] = b.z; in[4] = b.w;
+            in[5] = d.x; in[6] = d.y; in[7] = d.z; in[8] = d.w; in[9] = e;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int k = c * 9 + ky * 3 + kx;
+                const float4 w0 = *reinterpret_cast<const float4 *>(&s_w[k][cg * 8]);
+                const float4 w1 = *reinterpret_cast<const float4 *>(&s_w[k][cg * 8 + 4]);
+#pragma unroll
+                for (int p = 0; p < PX; ++p) {
+                    const float v = in[p + kx];
+                    acc[p][0] += v * w0.x; acc[p][1] += v * w0.y; acc[p][2] += v * w0.z; acc[p][3] += v * w0.w;
+                    acc[p][4] += v * w1.x; acc[p][5] += v * w1.y; acc[p][6] += v * w1.z; acc[p][7] += v * w1.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        const int gx = x0 + pg * 8 + p;
+        if (gx < W) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaxf(acc[p][j], 0.f);
+            *reinterpret_cast<uint4 *>(y + (((int64_t)n * H + gy) * W + gx) * CO + cg * 8) = pack8(o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- wgrad
+// dw[co][ci][tap] = sum_px dy[px][co] * in[ci][px + tap];  db[co] = sum_px dy[px][co].
+// Block = 4 waves = one image row x 256 pixels; wave q sweeps its own 64 pixels.  Lane = output
+// channel, so dy loads are 128 contiguous bytes per pixel and the 27 input values of a pixel are
+// wave-uniform (the compiler keeps them on the scalar path: v_fmac with an SGPR operand).
+// Each block writes one slab of Co*28 floats; k_first_reduce sums the slabs in index order.
+constexpr int WG_PIX = 256;
+
+__global__ __launch_bounds__(256) void k_first_wgrad(const float *__restrict__ frame, const uint16_t *__restrict__ dy,
+                                                      float *__restrict__ slabs, int H, int W) {
+    const int n = blockIdx.z;
+    const int gy = blockIdx.y;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int co = threadIdx.x & 63;
+    const int xs = blockIdx.x * WG_PIX + q * 64;
+    const int64_t plane = (int64_t)H * W;
+    const float *fr = frame + (int64_t)n * 3 * plane;
+    float acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+    float accb = 0.f;
+    const int xe = min(xs + 64, W);
+    for (int x = xs; x < xe; ++x) {
+        const float g = bf2f(dy[(((int64_t)n * H + gy) * W + x) * CO + co]);
+        accb += g;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = gy + ky - 1;
+                const bool rowok = yy >= 0 && yy < H;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int xx = x + kx - 1;
+                    float v = 0.f;
+                    if (rowok && xx >= 0 && xx < W) v = fr[c * plane + (int64_t)yy * W + xx];
+                    acc[c * 9 + ky * 3 + kx] += g * v;
+                }
+            }
+    }
+    // combine the 4 waves through LDS in wave order (fixed order => deterministic)
+    __shared__ float s[4][28][CO];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) s[q][k][co] = acc[k];
+    s[q][27][co] = accb;
+    __syncthreads();
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    for (int i = threadIdx.x; i < 28 * CO; i += 256) {
+        const int k = i / CO, c = i % CO;
+        slabs[(int64_t)blk * 28 * CO + i] = (s[0][k][c] + s[1][k][c]) + (s[2][k][c] + s[3][k][c]);
+    }
+}
+
+// out[co*27 + k] = sum over slabs of slab[k][co]; bias = row 27.  One thread per output, slabs
+// walked in index order with 4 independent partial chains (fixed association).
+__global__ __launch_bounds__(256) void k_first_reduce(const float *__restrict__ slabs, int n_slabs,
+                                                       float *__restrict__ dw, float *__restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 28 * CO) return;
+    const int k = i / CO, c = i % CO;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 3 < n_slabs; s += 4) {
+        a0 += slabs[(int64_t)(s + 0) * 28 * CO + i];
+        a1 += slabs[(int64_t)(s + 1) * 28 * CO + i];
+        a2 += slabs[(int64_t)(s + 2) * 28 * CO + i];
+        a3 += slabs[(int64_t)(s + 3) * 28 * CO + i];
+    }
+    for (; s < n_slabs; ++s) a0 += slabs[(int64_t)s * 28 * CO + i];
+    const float v = (a0 + a1) + (a2 + a3);
+    if (k < 27)
+        dw[c * 27 + k] = v;
+    else if (db)
+        db[c] = v;
+}
+}  // namespace
+
+extern "C" int fosvos_conv3x3_first_fwd(const float *frame, const float *w, const float *bias, uint16_t *y, int N,
+                                        int H, int W, int Co, int device, void *stream) {
+    FOSVOS_REQUIRE(frame && w && bias && y, FOSVOS_E_ARG, "conv3x3_first_fwd: null pointer");
+    FOSVOS_REQUIRE(Co == CO, FOSVOS_E_SHAPE, "conv3x3_first_fwd: Co=%d, only %d is built", Co, CO);
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && N <= 65535, FOSVOS_E_SHAPE, "conv3x3_first_fwd: bad shape N=%d H=%d W=%d",
+                   N, H, W);
+    FOSVOS_ENTER(device);
+    dim3 grid((unsigned)cdiv(W, TW), (unsigned)cdiv(H, ROWS), (unsigned)N);
+    hipLaunchKernelGGL(k_first_fwd, grid, dim3(256), 0, (hipStream_t)stream, frame, w, bias, y, H, W);
+    FOSVOS_LAUNCH_CHECK();
+    return FOSVOS_OK;
+}
+
+extern "C" size_t fosvos_conv3x3_first_wgrad_workspace_bytes(int N, int H, int W, int Co) {
+    return (size_t)N * H * cdiv(W, WG_PIX) * 28 * (size_t)Co * sizeof(float);
+}
+
+extern "C" int fosvos_conv3x3_first_wgrad(const float *frame, const uint16_t *dy, float *dw, float *db, int N, int H,
+                                          int W, int Co, void *workspace, size_t workspace_bytes, int device,
+                                          void *stream) {
+    FOSVOS_REQUIRE(frame && dy && dw && workspace, FOSVOS_E_ARG, "conv3x3_first_wgrad: null pointer");
+    FOSVOS_REQUIRE(Co == CO, FOSVOS_E_SHAPE, "conv3x3_first_wgrad: Co=%d, only %d is built", Co, CO);
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && N <= 65535 && H <= 65535, FOSVOS_E_SHAPE,
+                   "conv3x3_first_wgrad: bad shape N=%d H=%d W=%d", N, H, W);
+    const size_t need = fosvos_conv3x3_first_wgrad_workspace_bytes(N, H, W, Co);
+    FOSVOS_REQUIRE(workspace_bytes >= need, FOSVOS_E_WORKSPACE, "conv3x3_first_wgrad: workspace %zu < %zu",
+                   workspace_bytes, need);
+    FOSVOS_ENTER(device);
+    dim3 grid((unsigned)cdiv(W, WG_PIX), (unsigned)H, (unsigned)N);
+    float *slabs = reinterpret_cast<float *>(workspace);
+    hipLaunchKernelGGL(k_first_wgrad, grid, dim3(256), 0, (hipStream_t)stream, frame, dy, slabs, H, W);
+    FOSVOS_LAUNCH_CHECK();
+    const int n_slabs = (int)(grid.x * grid.y * grid.z);
+    hipLaunchKernelGGL(k_first_reduce, dim3((unsigned)cdiv(28 * CO, 256)), dim3(256), 0, (hipStream_t)stream, slabs,
+                       n_slabs, dw, db);
+    FOSVOS_LAUNCH_CHECK();
+    return FOSVOS_OK;
+}

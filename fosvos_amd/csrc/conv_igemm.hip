@@ -1,0 +1,308 @@
+// 3x3 / pad 1 / stride 1 convolution on bf16 NHWC as an implicit GEMM on the CDNA4 matrix cores
+// (v_mfma_f32_16x16x32_bf16, fp32 accumulate).  One kernel serves
+//   forward  : Conv2d(3x3)+bias[+ReLU]       (src/networks/osvos_vgg.py:42,92-93)
+//   dgrad    : the same contraction on the rotated/transposed filter image, with the ReLU
+//              backward of the producing layer and the "other consumer" gradient add fused into
+//              the epilogue.
+//
+// Decomposition (MFMA roofline; GEMM view M = pixels, N = out channels, K = 9 * in channels):
+//   workgroup = 256 threads = 4 waves, output tile = TH x TW pixels x BN channels;
+//   K loop over chunks of 32 input channels: the (TH+2) x (TW+2) input halo tile is staged into
+//   LDS ONCE per chunk and re-read for all 9 taps (im2col exists only as LDS addressing, never in
+//   HBM); the 9 x 32 x BN weight tile comes from the pre-packed image in contiguous 16-byte runs.
+//   An M fragment = 16 consecutive pixels of one tile row, so a tap shift is a pixel-index offset.
+//
+// LDS images (16-byte slots = 8 bf16 channels):
+//   A  [4 k-groups][NPIX_PAD pixels]      slot = kg * NPIX_PAD + P      (NPIX_PAD % 16 == 0)
+//   B  [9 taps][4 k-groups][BN channels]  slot = (tap*4 + kg) * BN + co
+// A ds_read_b128 fragment read (lane l: row l&15, k-group l>>4) then touches, per 16-lane service
+// group, 16 distinct slots of the 256-byte bank row for ANY base pixel: conflict-free for all taps.
+#include "common.hpp"
+
+using namespace fosvos;
+
+namespace {
+
+struct ConvArgs {
+    const uint16_t *x;         // [N,H,W,Cin] bf16, Cin % 32 == 0
+    const uint16_t *w;         // packed [Cin/32][9][4][Co_pad][8]
+    const float *bias;         // [Cout] or null
+    const uint16_t *relu_src;  // [N,H,W,Cout] or null
+    const uint16_t *addend;    // [N,H,W,Cout] or null
+    void *y;                   // [N,H,W,Cout] bf16 (or fp32)
+    int N, H, W, Cin, Cout, Co_pad;
+    int tiles_x, tiles_y;
+    unsigned flags;
+};
+
+template <int TH_, int TW_, int BN_, int WM_, int WN_>
+struct Tile {
+    static constexpr int TH = TH_, TW = TW_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int BM = TH * TW;
+    static constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
+    static constexpr int NPIX = HALO_W * HALO_H;
+    static constexpr int NPIX8 = (NPIX + 7) / 8 * 8;
+    static constexpr int NPIX_PAD = (NPIX + 15) / 16 * 16;
+    static constexpr int WAVE_M = BM / WM, WAVE_N = BN / WN;
+    static constexpr int MF = WAVE_M / 16, NF = WAVE_N / 16;
+    static constexpr int A_SLOTS = 4 * NPIX_PAD;
+    static constexpr int B_SLOTS = 36 * BN;
+    static constexpr int A_IT = (NPIX8 * 4 + 255) / 256;
+    static constexpr int B_IT = (B_SLOTS + 255) / 256;
+    static constexpr int OUT_LD = BN + 8;  // bf16 elements per staged output row (16-B aligned rows)
+    static constexpr int LDS_MAIN = (A_SLOTS + B_SLOTS) * 16;
+    static constexpr int LDS_OUT = BM * OUT_LD * 2;
+    static constexpr int LDS_BYTES = LDS_MAIN > LDS_OUT ? LDS_MAIN : LDS_OUT;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(TW % 16 == 0 && WAVE_M % 16 == 0 && WAVE_N % 16 == 0, "fragment alignment");
+    static_assert(BM % WM == 0 && BN % WN == 0, "wave split");
+};
+
+template <class T, bool OUT_F32>
+__global__ __launch_bounds__(256) void k_conv3x3_igemm(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    uint4 *sA = smem;
+    uint4 *sB = smem + T::A_SLOTS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / T::WN, wn = wave % T::WN;
+    int t = blockIdx.x;
+    const int tx_i = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty_i = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int y0 = ty_i * T::TH, x0 = tx_i * T::TW;
+    const int n0 = blockIdx.y * T::BN;
+    const int H = a.H, W = a.W, Cin = a.Cin;
+    const uint16_t *xn = a.x + (int64_t)n * H * W * Cin;
+
+    // ---- A staging plan: 8 consecutive lanes = 8 consecutive pixels of one k-group (conflict-free
+    // ds_write_b128), the 4 k-groups of those pixels in the next 3 octets (same 64-byte global runs)
+    int a_goff[T::A_IT];
+    int a_slot[T::A_IT];
+#pragma unroll
+    for (int it = 0; it < T::A_IT; ++it) {
+        const int idx = it * 256 + tid;
+        const int oct = idx >> 5, within = idx & 31;
+        const int kg = within >> 3;
+        const int P = oct * 8 + (within & 7);
+        a_goff[it] = -1;
+        a_slot[it] = -1;
+        if (P < T::NPIX) {
+            const int hy = P / T::HALO_W, hx = P - hy * T::HALO_W;
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            a_slot[it] = kg * T::NPIX_PAD + P;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) a_goff[it] = (gy * W + gx) * Cin + kg * 8;
+        }
+    }
+
+    f32x4 acc[T::MF][T::NF];
+#pragma unroll
+    for (int i = 0; i < T::MF; ++i)
+#pragma unroll
+        for (int j = 0; j < T::NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment base addresses (slots)
+    int a_base[T::MF];
+#pragma unroll
+    for (int i = 0; i < T::MF; ++i) {
+        const int pb = wm * T::WAVE_M + i * 16;
+        const int ty = pb / T::TW, tx = pb % T::TW;
+        a_base[i] = (lane >> 4) * T::NPIX_PAD + ty * T::HALO_W + tx + (lane & 15);
+    }
+    const int b_base = (lane >> 4) * T::BN + wn * T::WAVE_N + (lane & 15);
+
+    const int n_chunks = Cin >> 5;
+    for (int cc = 0; cc < n_chunks; ++cc) {
+        if (cc > 0) __syncthreads();
+        // ---- stage A (input halo tile, zero outside the image)
+#pragma unroll
+        for (int it = 0; it < T::A_IT; ++it) {
+            if (a_slot[it] >= 0) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (a_goff[it] >= 0) v = *reinterpret_cast<const uint4 *>(xn + a_goff[it] + cc * 32);
+                sA[a_slot[it]] = v;
+            }
+        }
+        // ---- stage B (weights: [tap*4+kg] rows of Co_pad slots, BN of them for this block)
+        const uint4 *wsrc = reinterpret_cast<const uint4 *>(a.w) + (int64_t)cc * 36 * a.Co_pad + n0;
+#pragma unroll
+        for (int it = 0; it < T::B_IT; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx < T::B_SLOTS) {
+                const int row = idx / T::BN, col = idx % T::BN;
+                sB[idx] = wsrc[(int64_t)row * a.Co_pad + col];
+            }
+        }
+        __syncthreads();
+        // ---- 9 taps x (MF x NF) MFMAs
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            bf16x8 af[T::MF], bfr[T::NF];
+#pragma unroll
+            for (int i = 0; i < T::MF; ++i)
+                af[i] = __builtin_bit_cast(bf16x8, sA[a_base[i] + ky * T::HALO_W + kx]);
+#pragma unroll
+            for (int j = 0; j < T::NF; ++j)
+                bfr[j] = __builtin_bit_cast(bf16x8, sB[b_base + tap * 4 * T::BN + j * 16]);
+#pragma unroll
+            for (int i = 0; i < T::MF; ++i)
+#pragma unroll
+                for (int j = 0; j < T::NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue.  C/D layout: acc[i][j][r] = out[pixel wm*WAVE_M + 16 i + 4 (lane>>4) + r][channel wn*WAVE_N + 16 j + (lane&15)]
+    const int q = lane >> 4, cl = lane & 15;
+    if (OUT_F32) {
+        float *yo = reinterpret_cast<float *>(a.y);
+#pragma unroll
+        for (int j = 0; j < T::NF; ++j) {
+            const int co = n0 + wn * T::WAVE_N + j * 16 + cl;
+            const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int i = 0; i < T::MF; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pix = wm * T::WAVE_M + i * 16 + q * 4 + r;
+                    const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
+                    if (gy < H && gx < W) {
+                        float v = acc[i][j][r] + b;
+                        if (a.flags & FOSVOS_CONV_RELU) v = fmaxf(v, 0.f);
+                        yo[(((int64_t)n * H + gy) * W + gx) * a.Cout + co] = v;
+                    }
+                }
+        }
+        return;
+    }
+    __syncthreads();  // every wave is done with sA/sB: reuse the memory as the bf16 output tile
+    uint16_t *sO = reinterpret_cast<uint16_t *>(smem);
+#pragma unroll
+    for (int j = 0; j < T::NF; ++j) {
+        const int col = wn * T::WAVE_N + j * 16 + cl;
+        const float b = a.bias ? a.bias[n0 + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < T::MF; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pix = wm * T::WAVE_M + i * 16 + q * 4 + r;
+                float v = acc[i][j][r] + b;
+                if (a.flags & FOSVOS_CONV_RELU) v = fmaxf(v, 0.f);
+                sO[pix * T::OUT_LD + col] = f2bf(v);
+            }
+    }
+    __syncthreads();
+    constexpr int VEC_PER_PIX = T::BN / 8;
+    uint16_t *yo = reinterpret_cast<uint16_t *>(a.y);
+    for (int idx = tid; idx < T::BM * VEC_PER_PIX; idx += 256) {
+        const int pix = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
+        const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
+        if (gy >= H || gx >= W) continue;
+        const int64_t off = (((int64_t)n * H + gy) * W + gx) * a.Cout + n0 + cg * 8;
+        uint4 v = *reinterpret_cast<const uint4 *>(sO + pix * T::OUT_LD + cg * 8);
+        if (a.relu_src || a.addend) {
+            float f[8];
+            unpack8(v, f);
+            if (a.relu_src) {
+                float m[8];
+                unpack8(*reinterpret_cast<const uint4 *>(a.relu_src + off), m);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = m[e] > 0.f ? f[e] : 0.f;
+            }
+            if (a.addend) {
+                float ad[8];
+                unpack8(*reinterpret_cast<const uint4 *>(a.addend + off), ad);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += ad[e];
+            }
+            v = pack8(f);
+        }
+        *reinterpret_cast<uint4 *>(yo + off) = v;
+    }
+}
+
+template <class T, bool OUT_F32>
+int launch(const ConvArgs &a0, hipStream_t st) {
+    ConvArgs a = a0;
+    a.tiles_x = (int)cdiv(a.W, T::TW);
+    a.tiles_y = (int)cdiv(a.H, T::TH);
+    const int64_t tiles = (int64_t)a.tiles_x * a.tiles_y * a.N;
+    FOSVOS_REQUIRE(tiles <= 0x7fffffff && a.Cout % T::BN == 0, FOSVOS_E_SHAPE, "conv3x3: tile grid");
+    static bool attr_done = false;  // benign race: idempotent
+    if (!attr_done && T::LDS_BYTES > 64 * 1024) {
+        FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_igemm<T, OUT_F32>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_conv3x3_igemm<T, OUT_F32>), dim3((unsigned)tiles, (unsigned)(a.Cout / T::BN)), dim3(256),
+                       T::LDS_BYTES, st, a);
+    FOSVOS_LAUNCH_CHECK();
+    return FOSVOS_OK;
+}
+
+// tile configurations
+using TileBig = Tile<8, 32, 64, 4, 1>;    // 256 px x 64 ch: stages 1-3
+using TileMid = Tile<8, 16, 64, 2, 2>;    // 128 px x 64 ch: stage 4 (60 x 107)
+using TileSmall = Tile<4, 16, 64, 2, 2>;  //  64 px x 64 ch: stage 5 (30 x 54)
+using TileSide = Tile<8, 32, 16, 4, 1>;   // 256 px x 16 ch: side_prep at large maps
+using TileSideS = Tile<4, 16, 16, 4, 1>;  //  64 px x 16 ch: side_prep at small maps
+
+int dispatch(const ConvArgs &a, hipStream_t st) {
+    const bool f32 = (a.flags & FOSVOS_CONV_OUT_F32) != 0;
+    const int64_t pixels = (int64_t)a.N * a.H * a.W;
+    if (a.Cout % 64 == 0) {
+        FOSVOS_REQUIRE(!f32, FOSVOS_E_ARG, "conv3x3: fp32 output is only built for 16-channel outputs");
+        const int64_t blocks_big = cdiv(a.W, 32) * cdiv(a.H, 8) * a.N * (a.Cout / 64);
+        const int64_t blocks_mid = cdiv(a.W, 16) * cdiv(a.H, 8) * a.N * (a.Cout / 64);
+        if (blocks_big >= 512) return launch<TileBig, false>(a, st);
+        if (blocks_mid >= 384) return launch<TileMid, false>(a, st);
+        return launch<TileSmall, false>(a, st);
+    }
+    FOSVOS_REQUIRE(a.Cout == 16, FOSVOS_E_SHAPE, "conv3x3: output channels must be 16 or a multiple of 64 (got %d)",
+                   a.Cout);
+    FOSVOS_REQUIRE(a.relu_src == nullptr && a.addend == nullptr, FOSVOS_E_ARG, "conv3x3: 16-channel output has no mask/add epilogue");
+    if (pixels >= 256 * 256) {
+        return f32 ? launch<TileSide, true>(a, st) : launch<TileSide, false>(a, st);
+    }
+    return f32 ? launch<TileSideS, true>(a, st) : launch<TileSideS, false>(a, st);
+}
+
+int check_common(const void *x, const void *w, const void *y, int N, int H, int W, int in_ch, int out_ch,
+                 const char *who) {
+    FOSVOS_REQUIRE(x && w && y, FOSVOS_E_ARG, "%s: null pointer", who);
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && in_ch > 0 && out_ch > 0, FOSVOS_E_SHAPE, "%s: bad shape N=%d H=%d W=%d in=%d out=%d",
+                   who, N, H, W, in_ch, out_ch);
+    FOSVOS_REQUIRE(out_ch % 16 == 0, FOSVOS_E_SHAPE, "%s: output channels %d not a multiple of 16", who, out_ch);
+    FOSVOS_REQUIRE((int64_t)H * W * roundup(in_ch, 32) < 0x7fffffffLL && (int64_t)H * W * out_ch < 0x7fffffffLL,
+                   FOSVOS_E_SHAPE, "%s: one image exceeds 2^31 elements", who);
+    return FOSVOS_OK;
+}
+}  // namespace
+
+extern "C" size_t fosvos_conv3x3_workspace_bytes(int, int, int, int, int) { return 0; }
+
+extern "C" int fosvos_conv3x3_fwd(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int N, int H,
+                                  int W, int Ci, int Co, unsigned flags, void *, size_t, int device, void *stream) {
+    if (int rc = check_common(x, w_packed, y, N, H, W, Ci, Co, "conv3x3_fwd")) return rc;
+    FOSVOS_REQUIRE((flags & ~(FOSVOS_CONV_RELU | FOSVOS_CONV_OUT_F32)) == 0, FOSVOS_E_ARG, "conv3x3_fwd: unknown flags 0x%x", flags);
+    FOSVOS_ENTER(device);
+    ConvArgs a{};
+    a.x = x; a.w = w_packed; a.bias = bias; a.relu_src = nullptr; a.addend = nullptr; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = roundup(Ci, 32); a.Cout = Co; a.Co_pad = roundup(Co, 16); a.flags = flags;
+    return dispatch(a, (hipStream_t)stream);
+}
+
+extern "C" int fosvos_conv3x3_dgrad(const uint16_t *dy, const uint16_t *w_dgrad_packed, const uint16_t *relu_src,
+                                    const uint16_t *addend, uint16_t *dx, int N, int H, int W, int Ci, int Co, void *,
+                                    size_t, int device, void *stream) {
+    // contraction over the forward op's output channels (Co), result has its input channels (Ci)
+    if (int rc = check_common(dy, w_dgrad_packed, dx, N, H, W, Co, Ci, "conv3x3_dgrad")) return rc;
+    FOSVOS_ENTER(device);
+    ConvArgs a{};
+    a.x = dy; a.w = w_dgrad_packed; a.bias = nullptr; a.relu_src = relu_src; a.addend = addend; a.y = dx;
+    a.N = N; a.H = H; a.W = W; a.Cin = roundup(Co, 32); a.Cout = Ci; a.Co_pad = roundup(Ci, 16); a.flags = 0;
+    return dispatch(a, (hipStream_t)stream);
+}

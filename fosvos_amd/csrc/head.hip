@@ -1,0 +1,323 @@
+// Fused side-output head: 4 x (per-channel transposed conv k=2f, stride f) + centre crop + concat
+// + 1x1 fuse, and the optional score_dsn -> 1-channel transposed conv -> crop branch
+// (reference: src/networks/osvos_vgg.py:69-82, src/layers/osvos_layers.py:47-54).
+//
+// The reference materialises 4 x [N,16,~H,~W] deconv outputs, 4 crops and a [N,64,H,W] concat
+// (about 310 MB fp32 per 480x854 frame).  Here one kernel reads the four small side maps (8.7 MB,
+// L2-resident) and writes the logit maps only; HBM-bound on the fp32 output.
+//
+// Geometry per scale s (f = 2^(s+1), k = 2f): deconv output size (h+1)*f; output pixel Yo receives
+// input rows i1 = Yo/f (tap ky = Yo%f) and i0 = i1-1 (tap ky+f); the crop removes
+// top = floor(((h+1)f - H)/2) leading rows (same for columns).  Upscale weights enter as their
+// diagonal: filt[s] = [16][k][k] (one filter per channel), filt1[s] = [k][k].
+#include "common.hpp"
+
+using namespace fosvos;
+
+namespace {
+struct HeadGeom {
+    int hs[4], ws[4];    // side map sizes
+    int top[4], left[4]; // crop offsets in deconv-output coordinates
+};
+
+struct HeadPtrs {
+    const float *side[4];
+    const float *filt[4];
+    const float *filt1[4];
+};
+
+__host__ inline bool make_geom(const int hs[4], const int ws[4], int H, int W, HeadGeom &g) {
+    for (int s = 0; s < 4; ++s) {
+        const int f = 2 << s;
+        const int uh = (hs[s] + 1) * f, uw = (ws[s] + 1) * f;
+        if (hs[s] <= 0 || ws[s] <= 0 || uh < H || uw < W) return false;
+        g.hs[s] = hs[s];
+        g.ws[s] = ws[s];
+        g.top[s] = (uh - H) / 2;   // floor(d/2) leading pixels removed (src/layers/osvos_layers.py:47-54)
+        g.left[s] = (uw - W) / 2;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------- forward
+// One thread per output pixel; consecutive lanes = consecutive X, so output stores are coalesced
+// and neighbouring lanes share side-map pixels (served by L1/L2).
+template <bool WITH_SIDE_OUT>
+__global__ __launch_bounds__(256) void k_head_fwd(HeadPtrs p, HeadGeom g, const float *__restrict__ dsn_w,
+                                                   const float *__restrict__ dsn_b, const float *__restrict__ fuse_w,
+                                                   const float *__restrict__ fuse_b, float *__restrict__ fused,
+                                                   float *so0, float *so1, float *so2, float *so3, int H, int W,
+                                                   int64_t total) {
+    __shared__ float s_fw[64], s_dw[64];
+    if (threadIdx.x < 64) {
+        s_fw[threadIdx.x] = fuse_w[threadIdx.x];
+        s_dw[threadIdx.x] = WITH_SIDE_OUT ? dsn_w[threadIdx.x] : 0.f;
+    }
+    __syncthreads();
+    float *so[4] = {so0, so1, so2, so3};
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int X = (int)(idx % W);
+        const int64_t r = idx / W;
+        const int Y = (int)(r % H);
+        const int64_t n = r / H;
+        float out = fuse_b[0];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int f = 2 << s, k = 4 << s;
+            const int Yo = Y + g.top[s], Xo = X + g.left[s];
+            const int i1 = Yo / f, j1 = Xo / f;
+            const int ky1 = Yo - i1 * f, kx1 = Xo - j1 * f;
+            const float *sd = p.side[s] + n * (int64_t)g.hs[s] * g.ws[s] * 16;
+            const float *fl = p.filt[s];
+            float so_acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int i = i1 - a, ky = ky1 + a * f;
+                if (i < 0 || i >= g.hs[s]) continue;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int j = j1 - b, kx = kx1 + b * f;
+                    if (j < 0 || j >= g.ws[s]) continue;
+                    const float4 *sp = reinterpret_cast<const float4 *>(sd + ((int64_t)i * g.ws[s] + j) * 16);
+                    float v[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 t = sp[q];
+                        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+                    }
+                    const float *fp = fl + ky * k + kx;
+                    float score = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        out += s_fw[16 * s + c] * (fp[c * k * k] * v[c]);
+                        if (WITH_SIDE_OUT) score += s_dw[16 * s + c] * v[c];
+                    }
+                    if (WITH_SIDE_OUT) so_acc += (score + dsn_b[s]) * p.filt1[s][ky * k + kx];
+                }
+            }
+            if (WITH_SIDE_OUT) so[s][idx] = so_acc;
+        }
+        fused[idx] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- backward
+// Per scale: one thread per (low-res pixel, channel); the 16 lanes of a pixel share the
+// 2f x 2f window of upstream gradients (broadcast loads) and each applies its own filter:
+//   T_c = sum_window filt[c][ky][kx] * d_fused[Y,X]      G = sum_window filt1[ky][kx] * d_side_out[Y,X]
+//   d_side[c]  = fuse_w[16s+c] * T_c + dsn_w[s][c] * G
+//   d_fuse_w[16s+c] += side[c] * T_c;  d_dsn_w[s][c] += side[c] * G;  d_dsn_b[s] += G
+// Block partials go to the workspace as slabs [block][3][16]; k_head_finish sums them in order.
+template <bool WITH_SIDE_OUT>
+__global__ __launch_bounds__(256) void k_head_bwd_scale(const float *__restrict__ side, const float *__restrict__ filt,
+                                                         const float *__restrict__ filt1,
+                                                         const float *__restrict__ fuse_w16,
+                                                         const float *__restrict__ dsn_w16,
+                                                         const float *__restrict__ d_fused,
+                                                         const float *__restrict__ d_so, uint16_t *__restrict__ d_side,
+                                                         float *__restrict__ slabs, int s, int hs, int ws, int top,
+                                                         int left, int H, int W, int64_t total /* N*hs*ws*16 */) {
+    const int f = 2 << s, k = 4 << s;
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int c = threadIdx.x & 15;
+    float T = 0.f, G = 0.f, sv = 0.f;
+    const bool active = idx < total;
+    if (active) {
+        const int64_t pix = idx >> 4;
+        const int j = (int)(pix % ws);
+        const int64_t r = pix / ws;
+        const int i = (int)(r % hs);
+        const int64_t n = r / hs;
+        const float *fc = filt + (int64_t)c * k * k;
+        const int Y0 = i * f - top, X0 = j * f - left;
+        const int ky_lo = max(0, -Y0), ky_hi = min(k, H - Y0);
+        const int kx_lo = max(0, -X0), kx_hi = min(k, W - X0);
+        for (int ky = ky_lo; ky < ky_hi; ++ky) {
+            const int64_t rowoff = (n * H + (Y0 + ky)) * W + X0;
+            for (int kx = kx_lo; kx < kx_hi; ++kx) {
+                if (d_fused) T += fc[ky * k + kx] * d_fused[rowoff + kx];
+                if (WITH_SIDE_OUT) G += filt1[ky * k + kx] * d_so[rowoff + kx];
+            }
+        }
+        sv = side[idx];
+        const float ds = fuse_w16[c] * T + (WITH_SIDE_OUT ? dsn_w16[c] * G : 0.f);
+        // padded 32-channel bf16 NHWC image: channel c and a zero in channel c+16
+        d_side[pix * 32 + c] = f2bf(ds);
+        d_side[pix * 32 + 16 + c] = 0;
+    }
+    // block reduction over lanes with equal c: xor 16, 32 inside the wave, then LDS across waves
+    float a = sv * T, b = WITH_SIDE_OUT ? sv * G : 0.f, g = (WITH_SIDE_OUT && c == 0) ? G : 0.f;
+    a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+    g += __shfl_xor(g, 16, 64); g += __shfl_xor(g, 32, 64);
+    __shared__ float red[4][3][16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 16) {
+        red[wave][0][lane] = a;
+        red[wave][1][lane] = b;
+        red[wave][2][lane] = g;
+    }
+    __syncthreads();
+    if (threadIdx.x < 48) {
+        const int q = threadIdx.x / 16, cc = threadIdx.x % 16;
+        slabs[(int64_t)blockIdx.x * 48 + threadIdx.x] = (red[0][q][cc] + red[1][q][cc]) + (red[2][q][cc] + red[3][q][cc]);
+    }
+}
+
+// per-block partial sums of d_fused (for d_fuse_b)
+__global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
+    float a = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a += x[i];
+    a = wave_sum(a);
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+struct FinishArgs {
+    const float *slabs[4];
+    int n_slabs[4];
+    const float *bias_partials;
+    int n_bias;
+};
+
+// One block per scale (+ one for the bias): thread t < 48 sums column t of the scale's slabs in
+// index order (fp64), deterministic.
+__global__ __launch_bounds__(64) void k_head_finish(FinishArgs fa, float *__restrict__ d_fuse_w,
+                                                     float *__restrict__ d_fuse_b, float *__restrict__ d_dsn_w,
+                                                     float *__restrict__ d_dsn_b) {
+    const int s = blockIdx.x;
+    if (s == 4) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < fa.n_bias; i += 64) acc += (double)fa.bias_partials[i];
+        acc = wave_sum(acc);
+        if (threadIdx.x == 0) d_fuse_b[0] = (float)acc;
+        return;
+    }
+    if (threadIdx.x >= 48) return;
+    const int q = threadIdx.x / 16, c = threadIdx.x % 16;
+    double acc = 0.0;
+    for (int b = 0; b < fa.n_slabs[s]; ++b) acc += (double)fa.slabs[s][(int64_t)b * 48 + threadIdx.x];
+    if (q == 0) d_fuse_w[16 * s + c] = (float)acc;
+    if (q == 1 && d_dsn_w) d_dsn_w[16 * s + c] = (float)acc;
+    if (q == 2 && d_dsn_b && c == 0) d_dsn_b[s] = (float)acc;
+}
+
+constexpr int kBiasBlocks = 512;
+}  // namespace
+
+extern "C" int fosvos_head_fwd(const float *const side[4], const int hs[4], const int ws[4],
+                               const float *const filt[4], const float *const filt1[4], const float *dsn_w,
+                               const float *dsn_b, const float *fuse_w, const float *fuse_b, float *fused,
+                               float *const side_out[4], int N, int H, int W, int device, void *stream) {
+    FOSVOS_REQUIRE(side && hs && ws && filt && fuse_w && fuse_b && fused, FOSVOS_E_ARG, "head_fwd: null pointer");
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0, FOSVOS_E_SHAPE, "head_fwd: bad shape N=%d H=%d W=%d", N, H, W);
+    const bool with_so = side_out && side_out[0];
+    HeadPtrs p;
+    for (int s = 0; s < 4; ++s) {
+        FOSVOS_REQUIRE(side[s] && filt[s], FOSVOS_E_ARG, "head_fwd: null side/filter pointer at scale %d", s);
+        p.side[s] = side[s];
+        p.filt[s] = filt[s];
+        p.filt1[s] = (with_so && filt1) ? filt1[s] : nullptr;
+        if (with_so)
+            FOSVOS_REQUIRE(side_out[s] && filt1 && filt1[s] && dsn_w && dsn_b, FOSVOS_E_ARG,
+                           "head_fwd: side outputs need all four buffers, filt1, dsn_w and dsn_b");
+    }
+    HeadGeom g;
+    FOSVOS_REQUIRE(make_geom(hs, ws, H, W, g), FOSVOS_E_SHAPE,
+                   "head_fwd: side map sizes (%d,%d),(%d,%d),(%d,%d),(%d,%d) do not cover %dx%d", hs[0], ws[0], hs[1],
+                   ws[1], hs[2], ws[2], hs[3], ws[3], H, W);
+    FOSVOS_ENTER(device);
+    const int64_t total = (int64_t)N * H * W;
+    int64_t blocks = cdiv(total, 256);
+    if (blocks > 65536) blocks = 65536;
+    if (with_so)
+        hipLaunchKernelGGL(k_head_fwd<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, dsn_w, dsn_b,
+                           fuse_w, fuse_b, fused, side_out[0], side_out[1], side_out[2], side_out[3], H, W, total);
+    else
+        hipLaunchKernelGGL(k_head_fwd<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, dsn_w,
+                           dsn_b, fuse_w, fuse_b, fused, (float *)nullptr, (float *)nullptr, (float *)nullptr,
+                           (float *)nullptr, H, W, total);
+    FOSVOS_LAUNCH_CHECK();
+    return FOSVOS_OK;
+}
+
+static inline size_t head_slab_floats(int N, int H, int W, size_t off[5]) {
+    // side sizes are ceil-halved four times; take the worst case the model can produce
+    size_t total = 0;
+    int h = H, w = W;
+    for (int s = 0; s < 4; ++s) {
+        h = (h + 1) / 2;
+        w = (w + 1) / 2;
+        off[s] = total;
+        total += (size_t)cdiv((int64_t)N * h * w * 16, 256) * 48;
+    }
+    off[4] = total;
+    total += kBiasBlocks;
+    return total;
+}
+
+extern "C" size_t fosvos_head_bwd_workspace_bytes(int N, int H, int W) {
+    size_t off[5];
+    return head_slab_floats(N, H, W, off) * sizeof(float);
+}
+
+extern "C" int fosvos_head_bwd(const float *const side[4], const int hs[4], const int ws[4],
+                               const float *const filt[4], const float *const filt1[4], const float *dsn_w,
+                               const float *fuse_w, const float *d_fused, const float *const d_side_out[4],
+                               uint16_t *const d_side[4], float *d_fuse_w, float *d_fuse_b, float *d_dsn_w,
+                               float *d_dsn_b, int N, int H, int W, void *workspace, size_t workspace_bytes, int device,
+                               void *stream) {
+    FOSVOS_REQUIRE(side && hs && ws && filt && fuse_w && d_side && d_fuse_w && d_fuse_b && workspace, FOSVOS_E_ARG,
+                   "head_bwd: null pointer");
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0, FOSVOS_E_SHAPE, "head_bwd: bad shape N=%d H=%d W=%d", N, H, W);
+    const bool with_so = d_side_out && d_side_out[0];
+    FOSVOS_REQUIRE(d_fused || with_so, FOSVOS_E_ARG, "head_bwd: no upstream gradient given");
+    HeadGeom g;
+    FOSVOS_REQUIRE(make_geom(hs, ws, H, W, g), FOSVOS_E_SHAPE, "head_bwd: side map sizes do not cover %dx%d", H, W);
+    size_t off[5];
+    const size_t need = head_slab_floats(N, H, W, off) * sizeof(float);
+    FOSVOS_REQUIRE(workspace_bytes >= need, FOSVOS_E_WORKSPACE, "head_bwd: workspace %zu < %zu", workspace_bytes, need);
+    for (int s = 0; s < 4; ++s) {
+        FOSVOS_REQUIRE(side[s] && filt[s] && d_side[s], FOSVOS_E_ARG, "head_bwd: null pointer at scale %d", s);
+        FOSVOS_REQUIRE(hs[s] <= (((H - 1) >> (s + 1)) + 1) && ws[s] <= (((W - 1) >> (s + 1)) + 1), FOSVOS_E_SHAPE,
+                       "head_bwd: side map %d larger than the ceil-pooled size", s);
+        if (with_so)
+            FOSVOS_REQUIRE(d_side_out[s] && filt1 && filt1[s] && dsn_w && d_dsn_w && d_dsn_b, FOSVOS_E_ARG,
+                           "head_bwd: side-output gradients need all four, filt1, dsn_w, d_dsn_w and d_dsn_b");
+    }
+    FOSVOS_ENTER(device);
+    hipStream_t st = (hipStream_t)stream;
+    float *wsf = reinterpret_cast<float *>(workspace);
+    FinishArgs fa;
+    for (int s = 0; s < 4; ++s) {
+        const int64_t total = (int64_t)N * hs[s] * ws[s] * 16;
+        const int blocks = (int)cdiv(total, 256);
+        fa.slabs[s] = wsf + off[s];
+        fa.n_slabs[s] = blocks;
+        if (with_so)
+            hipLaunchKernelGGL(k_head_bwd_scale<true>, dim3(blocks), dim3(256), 0, st, side[s], filt[s], filt1[s],
+                               fuse_w + 16 * s, dsn_w + 16 * s, d_fused, d_side_out[s], d_side[s], wsf + off[s], s, hs[s],
+                               ws[s], g.top[s], g.left[s], H, W, total);
+        else
+            hipLaunchKernelGGL(k_head_bwd_scale<false>, dim3(blocks), dim3(256), 0, st, side[s], filt[s],
+                               (const float *)nullptr, fuse_w + 16 * s, (const float *)nullptr, d_fused,
+                               (const float *)nullptr, d_side[s], wsf + off[s], s, hs[s], ws[s], g.top[s], g.left[s], H, W,
+                               total);
+        FOSVOS_LAUNCH_CHECK();
+    }
+    fa.bias_partials = wsf + off[4];
+    fa.n_bias = 0;
+    if (d_fused) {
+        fa.n_bias = kBiasBlocks;
+        hipLaunchKernelGGL(k_sum_partials, dim3(kBiasBlocks), dim3(256), 0, st, d_fused, (int64_t)N * H * W,
+                           wsf + off[4]);
+        FOSVOS_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_head_finish, dim3(5), dim3(64), 0, st, fa, d_fuse_w, d_fuse_b, with_so ? d_dsn_w : nullptr,
+                       with_so ? d_dsn_b : nullptr);
+    FOSVOS_LAUNCH_CHECK();
+    return FOSVOS_OK;
+}

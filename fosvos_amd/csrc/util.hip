@@ -1,0 +1,181 @@
+// Layout conversion and weight packing kernels + library-wide state.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+namespace fosvos {
+thread_local char g_err[512] = "";
+}
+using namespace fosvos;
+
+extern "C" int fosvos_abi_version(void) { return FOSVOS_ABI_VERSION; }
+extern "C" const char *fosvos_last_error(void) { return fosvos::g_err; }
+extern "C" const char *fosvos_build_arch(void) { return "gfx950"; }
+
+// ------------------------------------------------------------------------------ layout conversion
+// One thread = one pixel x 8 output channels.  Reads are coalesced per channel plane (consecutive
+// lanes = consecutive w), the 16-byte store is coalesced across the 8-channel groups of a pixel row.
+__global__ void k_nchw_f32_to_nhwc_bf16(const float *__restrict__ src, uint16_t *__restrict__ dst, int C, int HW,
+                                         int Cpad, int64_t total /* N*HW*(Cpad/8) */) {
+    const int groups = Cpad >> 3;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // pixel fastest inside a group so that plane reads coalesce
+        const int64_t pix = i % HW;
+        const int64_t r = i / HW;
+        const int g = (int)(r % groups);
+        const int64_t n = r / groups;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = g * 8 + j;
+            f[j] = c < C ? src[(n * C + c) * HW + pix] : 0.f;
+        }
+        *reinterpret_cast<uint4 *>(dst + ((n * HW + pix) * Cpad + g * 8)) = pack8(f);
+    }
+}
+
+__global__ void k_nhwc_bf16_to_nchw_f32(const uint16_t *__restrict__ src, float *__restrict__ dst, int C, int HW,
+                                         int Cpad, int64_t total /* N*C*HW */) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i % HW;
+        const int64_t r = i / HW;
+        const int c = (int)(r % C);
+        const int64_t n = r / C;
+        dst[i] = bf2f(src[(n * HW + pix) * Cpad + c]);
+    }
+}
+
+__global__ void k_nhwc_f32_to_nchw_f32(const float *__restrict__ src, float *__restrict__ dst, int C, int HW,
+                                        int64_t total) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i % HW;
+        const int64_t r = i / HW;
+        const int c = (int)(r % C);
+        const int64_t n = r / C;
+        dst[i] = src[(n * HW + pix) * C + c];
+    }
+}
+
+__global__ void k_nchw_f32_to_nhwc_f32(const float *__restrict__ src, float *__restrict__ dst, int C, int HW,
+                                        int64_t total) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i % HW;
+        const int64_t r = i / HW;
+        const int c = (int)(r % C);
+        const int64_t n = r / C;
+        dst[(n * HW + pix) * C + c] = src[i];
+    }
+}
+
+static inline int grid_for(int64_t total, int block = 256, int cap = 8192) {
+    int64_t g = cdiv(total, block);
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+extern "C" int fosvos_nchw_f32_to_nhwc_bf16(const float *src, uint16_t *dst, int N, int C, int H, int W, int Cpad,
+                                            int device, void *stream) {
+    FOSVOS_REQUIRE(src && dst, FOSVOS_E_ARG, "nchw_f32_to_nhwc_bf16: null pointer");
+    FOSVOS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad % 8 == 0, FOSVOS_E_SHAPE,
+                   "nchw_f32_to_nhwc_bf16: bad shape N=%d C=%d H=%d W=%d Cpad=%d", N, C, H, W, Cpad);
+    FOSVOS_ENTER(device);
+    const int64_t total = (int64_t)N * H * W * (Cpad / 8);
+    hipLaunchKernelGGL(k_nchw_f32_to_nhwc_bf16, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
+                       H * W, Cpad, total);
+    FOSVOS_LAUNCH_CHECK();
+    return FOSVOS_OK;
+}
+
+extern "C" int fosvos_nhwc_bf16_to_nchw_f32(const uint16_t *src, float *dst, int N, int C, int H, int W, int Cpad,
+                                            int device, void *stream) {
+    FOSVOS_REQUIRE(src && dst, FOSVOS_E_ARG, "nhwc_bf16_to_nchw_f32: null pointer");
+    FOSVOS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, FOSVOS_E_SHAPE, "nhwc_bf16_to_nchw_f32: bad shape");
+    FOSVOS_ENTER(device);
+    const int64_t total = (int64_t)N * C * H * W;
+    hipLaunchKernelGGL(k_nhwc_bf16_to_nchw_f32, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
+                       H * W, Cpad, total);
+    FOSVOS_LAUNCH_CHECK();
+    return FOSVOS_OK;
+}
+
+extern "C" int fosvos_nhwc_f32_to_nchw_f32(const float *src, float *dst, int N, int C, int H, int W, int device,
+                                           void *stream) {
+    FOSVOS_REQUIRE(src && dst, FOSVOS_E_ARG, "nhwc_f32_to_nchw_f32: null pointer");
+    FOSVOS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, FOSVOS_E_SHAPE, "nhwc_f32_to_nchw_f32: bad shape");
+    FOSVOS_ENTER(device);
+    const int64_t total = (int64_t)N * C * H * W;
+    hipLaunchKernelGGL(k_nhwc_f32_to_nchw_f32, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
+                       H * W, total);
+    FOSVOS_LAUNCH_CHECK();
+    return FOSVOS_OK;
+}
+
+extern "C" int fosvos_nchw_f32_to_nhwc_f32(const float *src, float *dst, int N, int C, int H, int W, int device,
+                                           void *stream) {
+    FOSVOS_REQUIRE(src && dst, FOSVOS_E_ARG, "nchw_f32_to_nhwc_f32: null pointer");
+    FOSVOS_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, FOSVOS_E_SHAPE, "nchw_f32_to_nhwc_f32: bad shape");
+    FOSVOS_ENTER(device);
+    const int64_t total = (int64_t)N * C * H * W;
+    hipLaunchKernelGGL(k_nchw_f32_to_nhwc_f32, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
+                       H * W, total);
+    FOSVOS_LAUNCH_CHECK();
+    return FOSVOS_OK;
+}
+
+// ------------------------------------------------------------------------------ weight packing
+// Packed image: [K32 = ceil(in/32)][tap 9][kc 4][out_pad][8] bf16, where for the forward image
+// (in, out) = (Ci, Co) and element = w[co][ci][tap]; for the dgrad image (in, out) = (Co, Ci) and
+// element = w[co][ci][8 - tap].  One thread writes one 16-byte group of 8 contraction channels.
+__global__ void k_pack_w(const float *__restrict__ w, uint16_t *__restrict__ dst, int Co, int Ci, int in_ch,
+                         int out_ch, int out_pad, int transpose, int64_t total_groups) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_groups;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(i % out_pad);
+        int64_t r = i / out_pad;
+        const int kc = (int)(r & 3);
+        r >>= 2;
+        const int tap = (int)(r % 9);
+        const int k32 = (int)(r / 9);
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ic = k32 * 32 + kc * 8 + j;
+            float v = 0.f;
+            if (ic < in_ch && o < out_ch) {
+                if (!transpose)
+                    v = w[((int64_t)o * Ci + ic) * 9 + tap];  // co = o, ci = ic
+                else
+                    v = w[((int64_t)ic * Ci + o) * 9 + (8 - tap)];  // co = ic, ci = o
+            }
+            f[j] = v;
+        }
+        *reinterpret_cast<uint4 *>(dst + i * 8) = pack8(f);
+    }
+}
+
+extern "C" size_t fosvos_packed_weight_elems(int out_ch, int in_ch) {
+    return (size_t)roundup(in_ch, 32) * 9 * (size_t)roundup(out_ch, 16);
+}
+
+extern "C" int fosvos_pack_conv3x3_weights(const float *w, int Co, int Ci, uint16_t *w_fwd, uint16_t *w_dgrad,
+                                           int device, void *stream) {
+    FOSVOS_REQUIRE(w, FOSVOS_E_ARG, "pack_conv3x3_weights: null weight pointer");
+    FOSVOS_REQUIRE(Co > 0 && Ci > 0, FOSVOS_E_SHAPE, "pack_conv3x3_weights: bad shape Co=%d Ci=%d", Co, Ci);
+    FOSVOS_ENTER(device);
+    if (w_fwd) {
+        const int out_pad = roundup(Co, 16);
+        const int64_t groups = (int64_t)(roundup(Ci, 32) / 32) * 9 * 4 * out_pad;
+        hipLaunchKernelGGL(k_pack_w, dim3(grid_for(groups)), dim3(256), 0, (hipStream_t)stream, w, w_fwd, Co, Ci, Ci, Co,
+                           out_pad, 0, groups);
+        FOSVOS_LAUNCH_CHECK();
+    }
+    if (w_dgrad) {
+        const int out_pad = roundup(Ci, 16);
+        const int64_t groups = (int64_t)(roundup(Co, 32) / 32) * 9 * 4 * out_pad;
+        hipLaunchKernelGGL(k_pack_w, dim3(grid_for(groups)), dim3(256), 0, (hipStream_t)stream, w, w_dgrad, Co, Ci, Co, Ci,
+                           out_pad, 1, groups);
+        FOSVOS_LAUNCH_CHECK();
+    }
+    return FOSVOS_OK;
+}

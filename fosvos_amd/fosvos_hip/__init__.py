@@ -1,0 +1,115 @@
+"""ctypes binding of libfosvos_hip.so (the C ABI declared in include/fosvos_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, an exception is
+raised.  Nothing here imports the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
+
+ABI_VERSION = 1
+CONV_RELU = 1
+CONV_OUT_F32 = 2
+
+
+class FosvosHipError(RuntimeError):
+    pass
+
+
+class SgdEntry(ctypes.Structure):
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("momentum_buf", c_void_p), ("numel", c_int64),
+                ("lr", c_float), ("weight_decay", c_float)]
+
+
+_P4 = c_void_p * 4
+_I4 = c_int * 4
+
+# name -> (restype, argtypes); every entry point of include/fosvos_hip.h
+SIGNATURES = {
+    "fosvos_abi_version": (c_int, []),
+    "fosvos_last_error": (c_char_p, []),
+    "fosvos_build_arch": (c_char_p, []),
+    "fosvos_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fosvos_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fosvos_nhwc_f32_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fosvos_nchw_f32_to_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fosvos_pack_conv3x3_weights": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "fosvos_packed_weight_elems": (c_size_t, [c_int, c_int]),
+    "fosvos_conv3x3_first_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                         c_void_p]),
+    "fosvos_conv3x3_first_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                           c_void_p, c_size_t, c_int, c_void_p]),
+    "fosvos_conv3x3_first_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "fosvos_conv3x3_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_uint,
+                                   c_void_p, c_size_t, c_int, c_void_p]),
+    "fosvos_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "fosvos_conv3x3_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                     c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "fosvos_conv3x3_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_void_p, c_size_t, c_int, c_void_p]),
+    "fosvos_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "fosvos_maxpool2x2_ceil_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fosvos_maxpool2x2_ceil_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                           c_void_p]),
+    "fosvos_head_fwd": (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_void_p),
+                                POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                POINTER(c_void_p), c_int, c_int, c_int, c_int, c_void_p]),
+    "fosvos_head_bwd": (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_void_p),
+                                POINTER(c_void_p), c_void_p, c_void_p, c_void_p, POINTER(c_void_p),
+                                POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_void_p, c_size_t, c_int, c_void_p]),
+    "fosvos_head_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "fosvos_cbce_loss": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
+                                 c_int, c_void_p]),
+    "fosvos_cbce_workspace_bytes": (c_size_t, [c_int64]),
+    "fosvos_sgd_momentum_step": (c_int, [c_void_p, c_int, c_int64, c_float, c_int, c_int, c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the shared library; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise FosvosHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C fosvos_amd/csrc`.  There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+        got = handle.fosvos_abi_version()
+        if got != ABI_VERSION:
+            raise FosvosHipError(f"libfosvos_hip.so ABI {got} != binding ABI {ABI_VERSION}: rebuild")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().fosvos_last_error()
+        raise FosvosHipError(f"{what} failed (code {rc}): {msg.decode(errors='replace') if msg else ''}")
+
+
+def ptr_array4(ptrs) -> "ctypes.Array":
+    return _P4(*[c_void_p(p) for p in ptrs])
+
+
+def int_array4(vals) -> "ctypes.Array":
+    return _I4(*[int(v) for v in vals])

@@ -1,0 +1,278 @@
+"""Whole-network forward/backward of OSVOS-VGG on the HIP kernels, as ONE autograd node.
+
+The reference builds this graph out of ~60 stock torch.nn calls (src/networks/osvos_vgg.py:61-83);
+here the host issues the kernels directly (one Python frame per iteration, no per-layer autograd
+bookkeeping) and keeps every intermediate in the layouts the kernels want:
+
+  frame fp32 NCHW -> conv1_1 (fp32 VALU) -> bf16 NHWC activations -> MFMA convs / pools
+  -> side_prep (fp32 NHWC, 16 ch) -> fused head -> fp32 [N,1,H,W] logits x 5
+
+Backward walks the same chain in reverse: head -> per stage {side_prep wgrad+dgrad, conv wgrad+dgrad
+(ReLU backward fused into the dgrad / pool-backward epilogues), pool backward} -> conv1_1 wgrad.
+Weight masters stay fp32 (the nn.Parameters of the module); bf16 packed images are cached per
+parameter version.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+STAGE_CHANNELS = ((64, 64), (128, 128), (256, 256, 256), (512, 512, 512), (512, 512, 512))
+STAGE_IN = (3, 64, 128, 256, 512)
+SIDE_CH = 16
+
+
+def conv_module_index(stage: int, k: int) -> int:
+    return 2 * k + (0 if stage == 0 else 1)
+
+
+def param_names() -> List[str]:
+    """state_dict order of the reference (src/networks/osvos_vgg.py:50-56)."""
+    names = [f"upscale.{i}.weight" for i in range(4)] + [f"upscale_.{i}.weight" for i in range(4)]
+    for s, chans in enumerate(STAGE_CHANNELS):
+        for j in range(len(chans)):
+            m = conv_module_index(s, j)
+            names += [f"stages.{s}.{m}.weight", f"stages.{s}.{m}.bias"]
+    for i in range(4):
+        names += [f"side_prep.{i}.weight", f"side_prep.{i}.bias"]
+    for i in range(4):
+        names += [f"score_dsn.{i}.weight", f"score_dsn.{i}.bias"]
+    names += ["fuse.weight", "fuse.bias"]
+    return names
+
+
+PARAM_NAMES = param_names()
+PARAM_INDEX = {n: i for i, n in enumerate(PARAM_NAMES)}
+
+
+class PackedWeights:
+    """bf16 MFMA images of the 3x3 conv weights and the diagonal deconv filters, rebuilt only when
+    the fp32 master changed (tracked by tensor version + storage pointer)."""
+
+    def __init__(self) -> None:
+        self._cache: Dict[str, Tuple[Tuple[int, int], object]] = {}
+
+    @staticmethod
+    def _key(t: torch.Tensor) -> Tuple[int, int]:
+        return (t.data_ptr(), t._version)
+
+    def conv(self, name: str, w: torch.Tensor):
+        key = self._key(w)
+        hit = self._cache.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        packed = ops.pack_conv3x3_weights(w.detach(), True, True)
+        self._cache[name] = (key, packed)
+        return packed
+
+    def deconv_diag(self, name: str, w: torch.Tensor) -> torch.Tensor:
+        """[C,C,k,k] transposed-conv weight -> its diagonal [C,k,k].  The fast head kernel applies one
+        k x k filter per channel; the reference initialises these layers as diagonal bilinear filters and
+        freezes them (src/layers/osvos_layers.py:70-81, lr 0 at src/util/network_provider.py:154-155).
+        A weight with off-diagonal mass is refused loudly rather than silently mis-evaluated."""
+        key = self._key(w)
+        hit = self._cache.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        wd = w.detach()
+        c = wd.shape[0]
+        idx = torch.arange(c, device=wd.device)
+        diag = wd[idx, idx].contiguous()
+        if c > 1:
+            off = wd.abs().sum() - diag.abs().sum()
+            if float(off) != 0.0:
+                raise NotImplementedError(
+                    f"{name}: transposed-conv weight has off-diagonal (cross-channel) entries; the HIP head "
+                    f"implements the per-channel (diagonal) form the reference initialises and freezes")
+        self._cache[name] = (key, diag)
+        return diag
+
+
+def _conv_list():
+    """(stage, k, cin, cout, weight name, bias name) for the 13 backbone convs."""
+    out = []
+    for s, chans in enumerate(STAGE_CHANNELS):
+        cin = STAGE_IN[s]
+        for j, cout in enumerate(chans):
+            m = conv_module_index(s, j)
+            out.append((s, j, cin, cout, f"stages.{s}.{m}.weight", f"stages.{s}.{m}.bias"))
+            cin = cout
+    return out
+
+
+CONVS = _conv_list()
+
+
+class Saved:
+    __slots__ = ("frame", "conv_in", "conv_out", "pool_in", "feats", "side", "H", "W", "with_side_out", "filt", "filt1")
+
+
+def forward(P: Dict[str, torch.Tensor], packs: PackedWeights, x: torch.Tensor, with_side_out: bool = True,
+            keep: bool = True):
+    """Returns ([side_out x4 (or None), fused], Saved or None)."""
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError(f"OSVOS_VGG expects [N,3,H,W] frames, got {tuple(x.shape)}")
+    if not x.is_cuda:
+        raise RuntimeError("the HIP OSVOS_VGG runs on the GPU only: move the module and the frame to cuda "
+                           "(there is no CPU fallback)")
+    x = x.contiguous().float()
+    N, _, H, W = x.shape
+    sv = Saved() if keep else None
+    conv_in: List[torch.Tensor] = []
+    conv_out: List[torch.Tensor] = []
+    pool_in: List[Optional[torch.Tensor]] = []
+    feats: List[torch.Tensor] = []
+    side: List[torch.Tensor] = []
+    a: Optional[torch.Tensor] = None
+    ci_idx = 0
+    for s, chans in enumerate(STAGE_CHANNELS):
+        if s > 0:
+            pool_in.append(a)
+            a = ops.maxpool_fwd(a)
+        for j in range(len(chans)):
+            _, _, cin, cout, wn, bn = CONVS[ci_idx]
+            ci_idx += 1
+            if s == 0 and j == 0:
+                y = ops.conv3x3_first_fwd(x, P[wn].detach(), P[bn].detach())
+                conv_in.append(x)
+            else:
+                wf, _ = packs.conv(wn, P[wn])
+                y = ops.conv3x3_fwd(a, wf, P[bn].detach(), cin, cout, relu=True)
+                conv_in.append(a)
+            conv_out.append(y)
+            a = y
+        feats.append(a)
+        if s > 0:
+            i = s - 1
+            wf, _ = packs.conv(f"side_prep.{i}.weight", P[f"side_prep.{i}.weight"])
+            side.append(ops.conv3x3_fwd(a, wf, P[f"side_prep.{i}.bias"].detach(), chans[-1], SIDE_CH, relu=False,
+                                        out_f32=True))
+    filt = [packs.deconv_diag(f"upscale.{i}.weight", P[f"upscale.{i}.weight"]) for i in range(4)]
+    filt1 = [packs.deconv_diag(f"upscale_.{i}.weight", P[f"upscale_.{i}.weight"]).reshape(4 << i, 4 << i)
+             for i in range(4)]
+    dsn_w = torch.stack([P[f"score_dsn.{i}.weight"].detach().reshape(16) for i in range(4)]).contiguous()
+    dsn_b = torch.cat([P[f"score_dsn.{i}.bias"].detach().reshape(1) for i in range(4)]).contiguous()
+    fuse_w = P["fuse.weight"].detach().reshape(64).contiguous()
+    fuse_b = P["fuse.bias"].detach().reshape(1).contiguous()
+    fused, side_out = ops.head_fwd(side, filt, filt1, dsn_w, dsn_b, fuse_w, fuse_b, H, W, with_side_out=with_side_out)
+    if keep:
+        sv.frame = x
+        sv.conv_in, sv.conv_out, sv.pool_in, sv.feats, sv.side = conv_in, conv_out, pool_in, feats, side
+        sv.H, sv.W, sv.with_side_out = H, W, with_side_out
+        sv.filt, sv.filt1 = filt, filt1
+    outs = (side_out if side_out is not None else [None] * 4) + [fused]
+    return outs, sv
+
+
+def backward(P: Dict[str, torch.Tensor], packs: PackedWeights, sv: "Saved", d_outs: Sequence[Optional[torch.Tensor]],
+             need: Optional[Dict[str, bool]] = None) -> Dict[str, torch.Tensor]:
+    """Gradients of sum_i <d_outs[i], out_i> wrt every parameter except the (frozen-by-recipe)
+    transposed-conv weights.  d_outs[4] is the fused-logit gradient; d_outs[0..3] the side-output ones
+    (all four or none)."""
+    grads: Dict[str, torch.Tensor] = {}
+    d_fused = d_outs[4]
+    d_so = d_outs[:4]
+    have_so = [g is not None for g in d_so]
+    if any(have_so) and not all(have_so):
+        ref = next(g for g in d_so if g is not None)
+        d_so = [g if g is not None else torch.zeros_like(ref) for g in d_so]
+    with_so = any(have_so)
+    if d_fused is None and not with_so:
+        return grads
+    dsn_w = torch.stack([P[f"score_dsn.{i}.weight"].detach().reshape(16) for i in range(4)]).contiguous()
+    fuse_w = P["fuse.weight"].detach().reshape(64).contiguous()
+    d_side, d_fuse_w, d_fuse_b, d_dsn_w, d_dsn_b = ops.head_bwd(
+        sv.side, sv.filt, sv.filt1 if with_so else None, dsn_w if with_so else None, fuse_w,
+        d_fused.contiguous().float() if d_fused is not None else None,
+        [g.contiguous().float() for g in d_so] if with_so else None, sv.H, sv.W)
+    grads["fuse.weight"] = d_fuse_w.reshape(1, 64, 1, 1)
+    grads["fuse.bias"] = d_fuse_b
+    if with_so:
+        for i in range(4):
+            grads[f"score_dsn.{i}.weight"] = d_dsn_w[i].reshape(1, 16, 1, 1)
+            grads[f"score_dsn.{i}.bias"] = d_dsn_b[i:i + 1]
+
+    g_pool: Optional[torch.Tensor] = None  # gradient wrt the current stage's output coming from the next stage's pool
+    ci_idx = len(CONVS)
+    for s in range(4, -1, -1):
+        chans = STAGE_CHANNELS[s]
+        feat = sv.feats[s]
+        if s > 0:
+            i = s - 1
+            wn, bn = f"side_prep.{i}.weight", f"side_prep.{i}.bias"
+            dw, db = ops.conv3x3_wgrad(feat, d_side[i], chans[-1], SIDE_CH)
+            grads[wn], grads[bn] = dw, db
+            _, wd = packs.conv(wn, P[wn])
+            # gradient wrt the stage output: ReLU-masked side dgrad + what came back through the next pool
+            g = ops.conv3x3_dgrad(d_side[i], wd, chans[-1], SIDE_CH, relu_src=feat, addend=g_pool, out=g_pool)
+        else:
+            g = g_pool
+        for j in range(len(chans) - 1, -1, -1):
+            ci_idx -= 1
+            _, _, cin, cout, wn, bn = CONVS[ci_idx]
+            xin = sv.conv_in[ci_idx]
+            if s == 0 and j == 0:
+                dw, db = ops.conv3x3_first_wgrad(sv.frame, g)
+                grads[wn], grads[bn] = dw, db
+                break
+            dw, db = ops.conv3x3_wgrad(xin, g, cin, cout)
+            grads[wn], grads[bn] = dw, db
+            _, wd = packs.conv(wn, P[wn])
+            # the conv input is a ReLU output when it came from a conv (mask here); when it came from a pool the
+            # mask is applied by the pool backward below
+            relu_src = xin if j > 0 else None
+            g = ops.conv3x3_dgrad(g, wd, cin, cout, relu_src=relu_src)
+        if s > 0:
+            g_pool = ops.maxpool_bwd(sv.pool_in[s - 1], g, relu_mask=True)
+    return grads
+
+
+class _OSVOSFunction(torch.autograd.Function):
+    """One autograd node for the whole network.  Inputs: the frame and the 52 parameters in state_dict
+    order; outputs: the 5 logit maps."""
+
+    @staticmethod
+    def forward(ctx, packs: PackedWeights, with_side_out: bool, x: torch.Tensor, *params: torch.Tensor):
+        P = dict(zip(PARAM_NAMES, params))
+        outs, sv = forward(P, packs, x, with_side_out=with_side_out, keep=True)
+        ctx.sv = sv
+        ctx.packs = packs
+        ctx.P = P
+        ctx.set_materialize_grads(False)
+        ctx.with_side_out = with_side_out
+        if not with_side_out:
+            outs = [torch.empty(0, device=x.device) for _ in range(4)] + [outs[4]]
+            ctx.mark_non_differentiable(*outs[:4])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *d_outs):
+        if ctx.sv is None:
+            raise RuntimeError("OSVOS_VGG backward called but no activations were kept")
+        d = list(d_outs)
+        if not ctx.with_side_out:
+            d = [None] * 4 + [d[4]]
+        grads = backward(ctx.P, ctx.packs, ctx.sv, d)
+        ctx.sv = None  # free the activations
+        out = [None, None, None]
+        for name in PARAM_NAMES:
+            g = grads.get(name)
+            p = ctx.P[name]
+            if g is not None and tuple(g.shape) != tuple(p.shape):
+                g = g.reshape(p.shape)
+            out.append(g if p.requires_grad else None)
+        return tuple(out)
+
+
+def run(packs: PackedWeights, params: Sequence[torch.Tensor], x: torch.Tensor, with_side_out: bool = True):
+    """Forward through the HIP kernels.  With grad mode on and trainable parameters this records one
+    autograd node; otherwise (inference) nothing is kept."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        return list(_OSVOSFunction.apply(packs, with_side_out, x, *params))
+    outs, _ = forward(dict(zip(PARAM_NAMES, params)), packs, x, with_side_out=with_side_out, keep=False)
+    if not with_side_out:
+        outs = [torch.empty(0, device=x.device) for _ in range(4)] + [outs[4]]
+    return outs

@@ -1,0 +1,321 @@
+"""Tensor-level wrappers over the C ABI: check devices/dtypes/contiguity, pass raw pointers and the
+current HIP stream, raise on any non-zero return.  No arithmetic happens in Python here.
+
+Activations are torch.bfloat16 NHWC tensors ([N,H,W,C]); frames / logits are fp32 NCHW as in the
+reference; side maps are fp32 NHWC [N,h,w,16].
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import CONV_OUT_F32, CONV_RELU, check, int_array4, lib, ptr_array4
+
+_BF16 = torch.bfloat16
+_F32 = torch.float32
+
+
+def _need(t: torch.Tensor, dtype, what: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor must live on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{what}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{what}: tensor must be contiguous")
+    return t
+
+
+def _ctx(t: torch.Tensor) -> Tuple[int, int]:
+    dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    return dev, torch.cuda.current_stream(dev).cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _ru(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+class Workspace:
+    """Grow-only scratch buffer per device (the library never allocates)."""
+
+    def __init__(self) -> None:
+        self._buf = {}
+
+    def get(self, nbytes: int, device: torch.device) -> Tuple[Optional[int], int]:
+        if nbytes <= 0:
+            return None, 0
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(_ru(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf.data_ptr(), buf.numel()
+
+
+_WS = Workspace()
+
+
+# ------------------------------------------------------------------------------------------ layout
+def nchw_to_nhwc_bf16(x: torch.Tensor, c_pad: Optional[int] = None) -> torch.Tensor:
+    _need(x, _F32, "nchw_to_nhwc_bf16")
+    n, c, h, w = x.shape
+    c_pad = _ru(c, 8) if c_pad is None else c_pad
+    out = torch.empty((n, h, w, c_pad), dtype=_BF16, device=x.device)
+    dev, st = _ctx(x)
+    check(lib().fosvos_nchw_f32_to_nhwc_bf16(x.data_ptr(), out.data_ptr(), n, c, h, w, c_pad, dev, st), "nchw_f32_to_nhwc_bf16")
+    return out
+
+
+def nhwc_bf16_to_nchw(x: torch.Tensor, c: Optional[int] = None) -> torch.Tensor:
+    _need(x, _BF16, "nhwc_bf16_to_nchw")
+    n, h, w, c_pad = x.shape
+    c = c_pad if c is None else c
+    out = torch.empty((n, c, h, w), dtype=_F32, device=x.device)
+    dev, st = _ctx(x)
+    check(lib().fosvos_nhwc_bf16_to_nchw_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, c_pad, dev, st), "nhwc_bf16_to_nchw_f32")
+    return out
+
+
+def nhwc_f32_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    _need(x, _F32, "nhwc_f32_to_nchw")
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, h, w), dtype=_F32, device=x.device)
+    dev, st = _ctx(x)
+    check(lib().fosvos_nhwc_f32_to_nchw_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, dev, st), "nhwc_f32_to_nchw_f32")
+    return out
+
+
+def nchw_to_nhwc_f32(x: torch.Tensor) -> torch.Tensor:
+    _need(x, _F32, "nchw_to_nhwc_f32")
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), dtype=_F32, device=x.device)
+    dev, st = _ctx(x)
+    check(lib().fosvos_nchw_f32_to_nhwc_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, dev, st), "nchw_f32_to_nhwc_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ weights
+def pack_conv3x3_weights(w: torch.Tensor, want_fwd: bool = True, want_dgrad: bool = True):
+    """fp32 OIHW -> (fwd image, dgrad image) as flat bf16 tensors (None when not wanted)."""
+    _need(w, _F32, "pack_conv3x3_weights")
+    co, ci, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("pack_conv3x3_weights: 3x3 kernels only")
+    L = lib()
+    fwd = torch.empty(L.fosvos_packed_weight_elems(co, ci), dtype=_BF16, device=w.device) if want_fwd else None
+    dgr = torch.empty(L.fosvos_packed_weight_elems(ci, co), dtype=_BF16, device=w.device) if want_dgrad else None
+    dev, st = _ctx(w)
+    check(L.fosvos_pack_conv3x3_weights(w.data_ptr(), co, ci, _p(fwd), _p(dgr), dev, st), "pack_conv3x3_weights")
+    return fwd, dgr
+
+
+# ------------------------------------------------------------------------------------------ conv
+def conv3x3_first_fwd(frame: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _need(frame, _F32, "conv3x3_first_fwd frame"); _need(w, _F32, "conv3x3_first_fwd weight"); _need(b, _F32, "conv3x3_first_fwd bias")
+    n, c, h, wd = frame.shape
+    if c != 3 or tuple(w.shape[1:]) != (3, 3, 3):
+        raise ValueError("conv3x3_first_fwd: expects a 3-channel frame and [Co,3,3,3] weights")
+    co = w.shape[0]
+    y = torch.empty((n, h, wd, co), dtype=_BF16, device=frame.device)
+    dev, st = _ctx(frame)
+    check(lib().fosvos_conv3x3_first_fwd(frame.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), n, h, wd, co, dev, st),
+          "conv3x3_first_fwd")
+    return y
+
+
+def conv3x3_first_wgrad(frame: torch.Tensor, dy: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    _need(frame, _F32, "conv3x3_first_wgrad frame"); _need(dy, _BF16, "conv3x3_first_wgrad dy")
+    n, c, h, wd = frame.shape
+    co = dy.shape[3]
+    if tuple(dy.shape[:3]) != (n, h, wd):
+        raise ValueError("conv3x3_first_wgrad: dy shape mismatch")
+    L = lib()
+    dw = torch.empty((co, 3, 3, 3), dtype=_F32, device=frame.device)
+    db = torch.empty((co,), dtype=_F32, device=frame.device)
+    ws, wsn = _WS.get(L.fosvos_conv3x3_first_wgrad_workspace_bytes(n, h, wd, co), frame.device)
+    dev, st = _ctx(frame)
+    check(L.fosvos_conv3x3_first_wgrad(frame.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), n, h, wd, co, ws, wsn,
+                                       dev, st), "conv3x3_first_wgrad")
+    return dw, db
+
+
+def conv3x3_fwd(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], ci: int, co: int,
+                relu: bool = True, out_f32: bool = False) -> torch.Tensor:
+    _need(x, _BF16, "conv3x3_fwd x"); _need(w_packed, _BF16, "conv3x3_fwd packed weight")
+    n, h, wd, cx = x.shape
+    if cx != _ru(ci, 32):
+        raise ValueError(f"conv3x3_fwd: x has {cx} channels, expected {_ru(ci, 32)} (Ci={ci} padded to 32)")
+    L = lib()
+    if w_packed.numel() != L.fosvos_packed_weight_elems(co, ci):
+        raise ValueError("conv3x3_fwd: packed weight size does not match (Co, Ci)")
+    if bias is not None:
+        _need(bias, _F32, "conv3x3_fwd bias")
+        if bias.numel() != co:
+            raise ValueError("conv3x3_fwd: bias size")
+    y = torch.empty((n, h, wd, co), dtype=_F32 if out_f32 else _BF16, device=x.device)
+    flags = (CONV_RELU if relu else 0) | (CONV_OUT_F32 if out_f32 else 0)
+    ws, wsn = _WS.get(L.fosvos_conv3x3_workspace_bytes(n, h, wd, ci, co), x.device)
+    dev, st = _ctx(x)
+    check(L.fosvos_conv3x3_fwd(x.data_ptr(), w_packed.data_ptr(), _p(bias), y.data_ptr(), n, h, wd, ci, co, flags, ws, wsn,
+                               dev, st), "conv3x3_fwd")
+    return y
+
+
+def conv3x3_dgrad(dy: torch.Tensor, w_dgrad_packed: torch.Tensor, ci: int, co: int,
+                  relu_src: Optional[torch.Tensor] = None, addend: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx[N,H,W,Ci] = mask_{relu_src>0}(dgrad(dy)) + addend.  ``out`` may alias ``addend``."""
+    _need(dy, _BF16, "conv3x3_dgrad dy"); _need(w_dgrad_packed, _BF16, "conv3x3_dgrad packed weight")
+    n, h, wd, cy = dy.shape
+    if cy != _ru(co, 32):
+        raise ValueError(f"conv3x3_dgrad: dy has {cy} channels, expected {_ru(co, 32)}")
+    L = lib()
+    if w_dgrad_packed.numel() != L.fosvos_packed_weight_elems(ci, co):
+        raise ValueError("conv3x3_dgrad: packed weight size does not match (Ci, Co)")
+    shape = (n, h, wd, ci)
+    for t, nm in ((relu_src, "relu_src"), (addend, "addend"), (out, "out")):
+        if t is not None:
+            _need(t, _BF16, f"conv3x3_dgrad {nm}")
+            if tuple(t.shape) != shape:
+                raise ValueError(f"conv3x3_dgrad: {nm} shape {tuple(t.shape)} != {shape}")
+    dx = out if out is not None else torch.empty(shape, dtype=_BF16, device=dy.device)
+    ws, wsn = _WS.get(L.fosvos_conv3x3_workspace_bytes(n, h, wd, co, ci), dy.device)
+    dev, st = _ctx(dy)
+    check(L.fosvos_conv3x3_dgrad(dy.data_ptr(), w_dgrad_packed.data_ptr(), _p(relu_src), _p(addend), dx.data_ptr(), n, h, wd,
+                                 ci, co, ws, wsn, dev, st), "conv3x3_dgrad")
+    return dx
+
+
+def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ci: int, co: int, with_bias: bool = True,
+                  dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None, accumulate: bool = False):
+    _need(x, _BF16, "conv3x3_wgrad x"); _need(dy, _BF16, "conv3x3_wgrad dy")
+    n, h, wd, cx = x.shape
+    if cx != ci or tuple(dy.shape) != (n, h, wd, _ru(co, 32)):
+        raise ValueError(f"conv3x3_wgrad: shapes x={tuple(x.shape)} dy={tuple(dy.shape)} do not match Ci={ci} Co={co}")
+    L = lib()
+    if dw is None:
+        if accumulate:
+            raise ValueError("conv3x3_wgrad: accumulate needs an existing dw")
+        dw = torch.empty((co, ci, 3, 3), dtype=_F32, device=x.device)
+    if with_bias and db is None:
+        if accumulate:
+            raise ValueError("conv3x3_wgrad: accumulate needs an existing db")
+        db = torch.empty((co,), dtype=_F32, device=x.device)
+    _need(dw, _F32, "conv3x3_wgrad dw")
+    ws, wsn = _WS.get(L.fosvos_conv3x3_wgrad_workspace_bytes(n, h, wd, ci, co), x.device)
+    dev, st = _ctx(x)
+    check(L.fosvos_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(db) if with_bias else None, n, h, wd, ci, co,
+                                 1 if accumulate else 0, ws, wsn, dev, st), "conv3x3_wgrad")
+    return dw, (db if with_bias else None)
+
+
+# ------------------------------------------------------------------------------------------ pool
+def maxpool_fwd(x: torch.Tensor) -> torch.Tensor:
+    _need(x, _BF16, "maxpool_fwd")
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), dtype=_BF16, device=x.device)
+    dev, st = _ctx(x)
+    check(lib().fosvos_maxpool2x2_ceil_fwd(x.data_ptr(), y.data_ptr(), n, h, w, c, dev, st), "maxpool2x2_ceil_fwd")
+    return y
+
+
+def maxpool_bwd(x: torch.Tensor, dy: torch.Tensor, relu_mask: bool = True) -> torch.Tensor:
+    _need(x, _BF16, "maxpool_bwd x"); _need(dy, _BF16, "maxpool_bwd dy")
+    n, h, w, c = x.shape
+    if tuple(dy.shape) != (n, (h + 1) // 2, (w + 1) // 2, c):
+        raise ValueError("maxpool_bwd: dy shape mismatch")
+    dx = torch.empty_like(x)
+    dev, st = _ctx(x)
+    check(lib().fosvos_maxpool2x2_ceil_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, h, w, c, 1 if relu_mask else 0,
+                                           dev, st), "maxpool2x2_ceil_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------ head
+def head_fwd(side: Sequence[torch.Tensor], filt: Sequence[torch.Tensor], filt1: Optional[Sequence[torch.Tensor]],
+             dsn_w: Optional[torch.Tensor], dsn_b: Optional[torch.Tensor], fuse_w: torch.Tensor, fuse_b: torch.Tensor,
+             H: int, W: int, with_side_out: bool = True):
+    """side[s]: fp32 NHWC [N,hs,ws,16]; filt[s]: [16,k,k]; filt1[s]: [k,k]; dsn_w [4,16]; dsn_b [4];
+    fuse_w [64]; fuse_b [1].  Returns (fused [N,1,H,W], [4 side outputs] or None)."""
+    n = side[0].shape[0]
+    for s in range(4):
+        _need(side[s], _F32, "head_fwd side"); _need(filt[s], _F32, "head_fwd filt")
+        k = 4 << s
+        if side[s].shape[3] != 16 or tuple(filt[s].shape) != (16, k, k):
+            raise ValueError("head_fwd: side/filter shape")
+    _need(fuse_w, _F32, "head_fwd fuse_w"); _need(fuse_b, _F32, "head_fwd fuse_b")
+    dev_t = side[0].device
+    fused = torch.empty((n, 1, H, W), dtype=_F32, device=dev_t)
+    outs = None
+    so_ptrs = [None] * 4
+    f1_ptrs = [None] * 4
+    if with_side_out:
+        outs = [torch.empty((n, 1, H, W), dtype=_F32, device=dev_t) for _ in range(4)]
+        so_ptrs = [o.data_ptr() for o in outs]
+        for s in range(4):
+            _need(filt1[s], _F32, "head_fwd filt1")
+        f1_ptrs = [f.data_ptr() for f in filt1]
+        _need(dsn_w, _F32, "head_fwd dsn_w"); _need(dsn_b, _F32, "head_fwd dsn_b")
+    dev, st = _ctx(side[0])
+    check(lib().fosvos_head_fwd(ptr_array4([t.data_ptr() for t in side]), int_array4([t.shape[1] for t in side]),
+                                int_array4([t.shape[2] for t in side]), ptr_array4([t.data_ptr() for t in filt]),
+                                ptr_array4(f1_ptrs), _p(dsn_w) if with_side_out else None,
+                                _p(dsn_b) if with_side_out else None, fuse_w.data_ptr(), fuse_b.data_ptr(),
+                                fused.data_ptr(), ptr_array4(so_ptrs), n, H, W, dev, st), "head_fwd")
+    return fused, outs
+
+
+def head_bwd(side: Sequence[torch.Tensor], filt: Sequence[torch.Tensor], filt1: Optional[Sequence[torch.Tensor]],
+             dsn_w: Optional[torch.Tensor], fuse_w: torch.Tensor, d_fused: Optional[torch.Tensor],
+             d_side_out: Optional[Sequence[torch.Tensor]], H: int, W: int):
+    """Returns (d_side[4] bf16 NHWC [N,hs,ws,32], d_fuse_w[64], d_fuse_b[1], d_dsn_w[4,16]|None, d_dsn_b[4]|None)."""
+    n = side[0].shape[0]
+    dev_t = side[0].device
+    with_so = d_side_out is not None
+    if d_fused is not None:
+        _need(d_fused, _F32, "head_bwd d_fused")
+    d_side = [torch.empty((n, t.shape[1], t.shape[2], 32), dtype=_BF16, device=dev_t) for t in side]
+    d_fuse_w = torch.empty((64,), dtype=_F32, device=dev_t)
+    d_fuse_b = torch.empty((1,), dtype=_F32, device=dev_t)
+    d_dsn_w = torch.empty((4, 16), dtype=_F32, device=dev_t) if with_so else None
+    d_dsn_b = torch.empty((4,), dtype=_F32, device=dev_t) if with_so else None
+    dso_ptrs = [None] * 4
+    f1_ptrs = [None] * 4
+    if with_so:
+        for s in range(4):
+            _need(d_side_out[s], _F32, "head_bwd d_side_out"); _need(filt1[s], _F32, "head_bwd filt1")
+        dso_ptrs = [t.data_ptr() for t in d_side_out]
+        f1_ptrs = [t.data_ptr() for t in filt1]
+        _need(dsn_w, _F32, "head_bwd dsn_w")
+    L = lib()
+    ws, wsn = _WS.get(L.fosvos_head_bwd_workspace_bytes(n, H, W), dev_t)
+    dev, st = _ctx(side[0])
+    check(L.fosvos_head_bwd(ptr_array4([t.data_ptr() for t in side]), int_array4([t.shape[1] for t in side]),
+                            int_array4([t.shape[2] for t in side]), ptr_array4([t.data_ptr() for t in filt]),
+                            ptr_array4(f1_ptrs), _p(dsn_w) if with_so else None, fuse_w.data_ptr(), _p(d_fused),
+                            ptr_array4(dso_ptrs), ptr_array4([t.data_ptr() for t in d_side]), d_fuse_w.data_ptr(),
+                            d_fuse_b.data_ptr(), _p(d_dsn_w), _p(d_dsn_b), n, H, W, ws, wsn, dev, st), "head_bwd")
+    return d_side, d_fuse_w, d_fuse_b, d_dsn_w, d_dsn_b
+
+
+# ------------------------------------------------------------------------------------------ loss
+def cbce_loss(logits: torch.Tensor, label: torch.Tensor, size_average: bool = True, grad_scale: float = 1.0,
+              want_grad: bool = True):
+    """Returns (loss: 0-dim fp32 tensor on the device, grad like logits or None)."""
+    _need(logits, _F32, "cbce_loss logits"); _need(label, _F32, "cbce_loss label")
+    if logits.shape != label.shape:
+        raise ValueError(f"cbce_loss: logits {tuple(logits.shape)} vs label {tuple(label.shape)}")
+    L = lib()
+    loss = torch.empty((), dtype=_F32, device=logits.device)
+    grad = torch.empty_like(logits) if want_grad else None
+    # the loss keeps its own small workspace: it must stay valid until the kernels ran, and the shared
+    # grow-only buffer may be re-used by the next op on the same stream (which is ordered after us)
+    ws, wsn = _WS.get(L.fosvos_cbce_workspace_bytes(logits.numel()), logits.device)
+    dev, st = _ctx(logits)
+    check(L.fosvos_cbce_loss(logits.data_ptr(), label.data_ptr(), logits.numel(), 1 if size_average else 0,
+                             float(grad_scale), loss.data_ptr(), _p(grad), ws, wsn, dev, st), "cbce_loss")
+    return loss, grad

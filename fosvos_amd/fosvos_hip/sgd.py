@@ -1,0 +1,91 @@
+"""SGD with momentum on one multi-tensor HIP launch per step (fosvos_sgd_momentum_step).
+
+Same constructor and param-group semantics as ``torch.optim.SGD`` as the reference uses it
+(src/util/network_provider.py:98-125,144-159: momentum 0.9, per-group lr / weight_decay, no
+dampening, no nesterov).  It subclasses ``torch.optim.SGD`` so ``isinstance`` checks, ``param_groups``,
+``zero_grad`` and ``state_dict`` behave as callers expect; only ``step`` is replaced.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+from torch import optim
+
+from . import SgdEntry, check, lib
+
+
+class FusedSGD(optim.SGD):
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0, weight_decay=0.0, nesterov=False, **kw):
+        if dampening != 0 or nesterov:
+            raise NotImplementedError("FusedSGD implements the reference recipe: dampening=0, nesterov=False")
+        kw.pop("foreach", None)
+        kw.pop("fused", None)
+        super().__init__(params, lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
+                         nesterov=nesterov, **kw)
+        self._host_table = None
+        self._dev_table = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        entries = []
+        momentum = None
+        device = None
+        max_numel = 0
+        keep_alive = []
+        for group in self.param_groups:
+            if group.get("dampening", 0) != 0 or group.get("nesterov", False):
+                raise NotImplementedError("FusedSGD: dampening/nesterov are not implemented")
+            m = float(group["momentum"])
+            if momentum is None:
+                momentum = m
+            elif m != momentum:
+                raise NotImplementedError("FusedSGD: one momentum value for all groups (as in the reference recipe)")
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("FusedSGD: parameters must live on the GPU (no CPU fallback)")
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise TypeError("FusedSGD: fp32 contiguous parameters only")
+                g = p.grad
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.contiguous().float()
+                    keep_alive.append(g)
+                st = self.state[p]
+                buf = st.get("momentum_buffer")
+                if buf is None:
+                    # zero-initialised: momentum*0 + g == g, which is torch's "first step clones the gradient"
+                    buf = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["momentum_buffer"] = buf
+                device = p.device
+                entries.append((p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), float(group["lr"]),
+                                float(group["weight_decay"])))
+                max_numel = max(max_numel, p.numel())
+        if not entries:
+            return loss
+        n = len(entries)
+        nbytes = n * ctypes.sizeof(SgdEntry)
+        if self._host_table is None or self._host_table.numel() < nbytes:
+            self._host_table = torch.empty(max(nbytes, 4096), dtype=torch.uint8).pin_memory()
+            self._dev_table = torch.empty(max(nbytes, 4096), dtype=torch.uint8, device=device)
+        arr = (SgdEntry * n).from_address(self._host_table.data_ptr())
+        for i, e in enumerate(entries):
+            arr[i].param, arr[i].grad, arr[i].momentum_buf, arr[i].numel, arr[i].lr, arr[i].weight_decay = e
+        # NB: the pinned staging buffer is rewritten on the next step(); the copy below is stream-ordered before
+        # the kernel, and the next step's host write happens after this step's copy was issued - to be safe against
+        # an in-flight copy we synchronise on the copy event only when a previous one is still pending.
+        if getattr(self, "_copy_event", None) is not None:
+            self._copy_event.synchronize()
+        self._dev_table[:nbytes].copy_(self._host_table[:nbytes], non_blocking=True)
+        self._copy_event = torch.cuda.Event()
+        self._copy_event.record()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        check(lib().fosvos_sgd_momentum_step(self._dev_table.data_ptr(), n, max_numel, momentum, 0, idx,
+                                             torch.cuda.current_stream(idx).cuda_stream), "sgd_momentum_step")
+        del keep_alive
+        return loss

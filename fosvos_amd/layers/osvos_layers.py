@@ -1,0 +1,96 @@
+"""Drop-in for the reference's ``layers.osvos_layers`` (src/layers/osvos_layers.py): same function
+names, argument meaning and return values; the loss runs as one fused HIP kernel group.
+
+  class_balanced_cross_entropy_loss  src/layers/osvos_layers.py:17-44  -> fosvos_cbce_loss
+  center_crop                        src/layers/osvos_layers.py:47-54  (index arithmetic only)
+  upsample_filt / interp_surgery     src/layers/osvos_layers.py:57-81  (one-off host init)
+  logit / sigmoid_np                 src/layers/osvos_layers.py:9-14   (numpy helpers)
+"""
+from __future__ import division
+
+import math
+
+import numpy as np
+import torch
+from torch.nn import functional as F
+
+from fosvos_hip import ops
+
+
+def logit(x):
+    return np.log(x / (1 - x + 1e-08) + 1e-08)
+
+
+def sigmoid_np(x):
+    return 1 / (1 + np.exp(-x))
+
+
+class _CBCELoss(torch.autograd.Function):
+    """Loss value and d(loss)/d(logits) come out of the same kernel pass; backward only scales."""
+
+    @staticmethod
+    def forward(ctx, output, label, size_average):
+        loss, grad = ops.cbce_loss(output.contiguous().float(), label.contiguous().float(),
+                                   size_average=bool(size_average), want_grad=output.requires_grad)
+        ctx.grad = grad
+        ctx.shape = output.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.grad is None:
+            return None, None, None
+        return (ctx.grad * g).reshape(ctx.shape), None, None
+
+
+def class_balanced_cross_entropy_loss(output, label, size_average=True):
+    """Class-balanced cross entropy loss (same contract as the reference).
+
+    Args:
+    output: Output of the network (logits)
+    label: Ground truth label
+    Returns:
+    0-dim tensor with the loss; reductions run over the whole batch tensor."""
+    if not output.is_cuda:
+        raise RuntimeError("class_balanced_cross_entropy_loss: the HIP implementation needs GPU tensors "
+                           "(no CPU fallback)")
+    if label.device != output.device:
+        label = label.to(output.device)
+    if tuple(label.shape) != tuple(output.shape):
+        raise ValueError("class_balanced_cross_entropy_loss: output {} vs label {}".format(
+            tuple(output.shape), tuple(label.shape)))
+    return _CBCELoss.apply(output, label, size_average)
+
+
+def crop_offsets(size, target):
+    """Pixels removed in front / behind by the reference's centre crop: floor(d/2) and ceil(d/2)."""
+    d = size - target
+    return -int(math.ceil(-d / 2.0)), -int(math.floor(-d / 2.0))
+
+
+def center_crop(x, height, width):
+    top, bottom = crop_offsets(int(x.size()[2]), height)
+    left, right = crop_offsets(int(x.size()[3]), width)
+    return F.pad(x, [-left, -right, -top, -bottom])
+
+
+def upsample_filt(size):
+    factor = (size + 1) // 2
+    center = factor - 1 if size % 2 == 1 else factor - 0.5
+    t = 1 - np.abs(np.arange(size) - center) / factor
+    return t[:, None] * t[None, :]
+
+
+def interp_surgery(lay):
+    """Set a ConvTranspose2d so that it computes bilinear interpolation (diagonal, no groups)."""
+    m, k, h, w = lay.weight.data.size()
+    if m != k:
+        raise Exception('input + output channels need to be the same')
+    if h != w:
+        raise Exception('filters need to be square')
+    filt = torch.from_numpy(upsample_filt(h)).to(lay.weight.data.dtype)
+    with torch.no_grad():
+        lay.weight.data.zero_()
+        idx = torch.arange(m)
+        lay.weight.data[idx, idx] = filt.to(lay.weight.data.device)
+    return lay.weight.data

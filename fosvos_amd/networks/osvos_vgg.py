@@ -1,0 +1,130 @@
+"""Drop-in for the reference's ``networks.osvos_vgg.OSVOS_VGG`` (src/networks/osvos_vgg.py:17-153).
+
+Same constructor, same sub-module attribute names (stages, side_prep, score_dsn, upscale, upscale_,
+fuse), same 52-tensor state_dict (keys, shapes, order) and the same ``forward(x) -> list of 5
+[N,1,H,W] logit maps``.  The sub-modules are stock torch.nn containers that only HOLD the fp32
+parameters (so optimizers, checkpoints and code that walks ``net.stages`` keep working); the
+arithmetic of forward/backward runs in the hand-written HIP kernels through fosvos_hip.engine.
+"""
+import os
+from copy import deepcopy
+
+import torch
+import torch.nn as nn
+import torch.nn.modules as modules
+
+from fosvos_hip import engine
+from layers.osvos_layers import interp_surgery
+from util.logger import get_logger
+
+log = get_logger(__file__)
+
+
+class OSVOS_VGG(nn.Module):
+    def __init__(self, pretrained=1):
+        super(OSVOS_VGG, self).__init__()
+        lay_list = [[64, 64],
+                    ['M', 128, 128],
+                    ['M', 256, 256, 256],
+                    ['M', 512, 512, 512],
+                    ['M', 512, 512, 512]]
+        in_channels = [3, 64, 128, 256, 512]
+
+        log.info("Constructing OSVOS architecture...")
+        stages = modules.ModuleList()
+        side_prep = modules.ModuleList()
+        score_dsn = modules.ModuleList()
+        upscale = modules.ModuleList()
+        upscale_ = modules.ModuleList()
+        for i, cfg in enumerate(lay_list):
+            stages.append(self._make_layers_osvos(cfg, in_channels[i]))
+            if i > 0:  # side branches hang off stages 2..5
+                side_prep.append(nn.Conv2d(cfg[-1], 16, kernel_size=3, padding=1))
+                score_dsn.append(nn.Conv2d(16, 1, kernel_size=1, padding=0))
+                upscale_.append(nn.ConvTranspose2d(1, 1, kernel_size=2 ** (1 + i), stride=2 ** i, bias=False))
+                upscale.append(nn.ConvTranspose2d(16, 16, kernel_size=2 ** (1 + i), stride=2 ** i, bias=False))
+
+        # registration order fixes the state_dict order
+        self.upscale = upscale
+        self.upscale_ = upscale_
+        self.stages = stages
+        self.side_prep = side_prep
+        self.score_dsn = score_dsn
+        self.fuse = nn.Conv2d(64, 1, kernel_size=1, padding=0)
+
+        self._packs = engine.PackedWeights()  # bf16 MFMA images of the weights, rebuilt when a master changes
+
+        log.info("Initializing weights")
+        self._initialize_weights(pretrained)
+
+    # ------------------------------------------------------------------ forward on the HIP kernels
+    def forward(self, x):
+        """list of 5 logit maps [N,1,H,W]: the 4 side outputs then the fused output."""
+        sd = dict(self.named_parameters())
+        params = [sd[name] for name in engine.PARAM_NAMES]
+        return engine.run(self._packs, params, x, with_side_out=True)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop('_packs', None)  # whole-module pickles (NetworkProvider.save_model) carry no device caches
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._packs = engine.PackedWeights()
+
+    # ------------------------------------------------------------------ structure / init (host side)
+    @staticmethod
+    def _make_layers_osvos(cfg, in_channels):
+        layers = []
+        for v in cfg:
+            if v == 'M':
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2, ceil_mode=True))
+            else:
+                layers.extend([nn.Conv2d(in_channels, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)])
+                in_channels = v
+        return nn.Sequential(*layers)
+
+    def _initialize_weights(self, pretrained):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.data.normal_(0, 0.001)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, nn.ConvTranspose2d):
+                m.weight.data.zero_()
+                m.weight.data = interp_surgery(m)
+
+        if pretrained == 1:
+            self._load_from_pytorch()
+        elif pretrained == 2:
+            self._load_from_caffe()
+
+    def _load_from_pytorch(self):
+        log.info('Loading weights from PyTorch VGG')
+        try:
+            from torchvision.models import vgg16
+        except ImportError as e:  # torchvision is not part of this image
+            raise RuntimeError("OSVOS_VGG(pretrained=1) copies torchvision's ImageNet VGG-16, which needs "
+                               "torchvision and network access; use pretrained=0 + load_state_dict, or "
+                               "pretrained=2 with vgg_hed_caffe.mat") from e
+        _vgg = vgg16(pretrained=True)
+        src = [m for m in _vgg.features if isinstance(m, nn.Conv2d)]
+        dst = [m for stage in self.stages for m in stage if isinstance(m, nn.Conv2d)]
+        for d, s in zip(dst, src):
+            d.weight = deepcopy(s.weight)
+            d.bias = deepcopy(s.bias)
+
+    def _load_from_caffe(self):
+        log.info('Loading weights from Caffe VGG')
+        import scipy.io
+        from config.mypath import Path
+        caffe_weights = scipy.io.loadmat(os.path.join(Path.models_dir(), 'vgg_hed_caffe.mat'))
+        convs = [m for stage in self.stages for m in stage if isinstance(m, nn.Conv2d)]
+        for k, conv in enumerate(convs):
+            c_w = torch.from_numpy(caffe_weights['weights'][0][k].transpose())
+            c_b = torch.from_numpy(caffe_weights['biases'][0][k][:, 0])
+            assert conv.weight.data.shape == c_w.shape
+            assert conv.bias.data.shape == c_b.shape
+            conv.weight.data = c_w
+            conv.bias.data = c_b

@@ -1,0 +1,90 @@
+"""Multi-GPU support for the fine-tune loop: one process per GPU, torch.distributed over RCCL
+("nccl" backend on ROCm) on xGMI, gloo on CPU for tests.
+
+The reference has no collective at all: its only multi-device mechanism is launching
+independent processes that shard the sequence list (src/train_online.py:184-186).  Two modes here:
+
+* replicas: each rank fine-tunes its own sequences, no data-path collective (``shard_sequences``).
+* data parallel inside one sequence (``FlatGrads.all_reduce``): the ``avg_grad_every_n`` accumulation
+  micro-batches are spread over the ranks and the gradients are SUM-all-reduced once per optimizer
+  step; with ``world * local_accum == avg_grad_every_n`` this reproduces the single-process update
+  (src/train_online.py:92-101) up to fp32 summation order.
+
+Gradients live in ONE flat fp32 buffer (each ``p.grad`` is a view), so the all-reduce is a single
+59.7 MB collective instead of 26 small ones, and zeroing is one memset.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None) -> bool:
+    """Initialise the default process group from the torchrun environment; False when single-process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return False
+    if dist.is_initialized():
+        return True
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend)
+    return True
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_sequences(sequences: Sequence[str], group: Optional[int], group_size: Optional[int]) -> List[str]:
+    """The reference's -sg/-sgs sharding: sequence i goes to group i % group_size
+    (src/train_online.py:178-186)."""
+    if group is None:
+        return list(sequences)
+    return [s for i, s in enumerate(sequences) if i % group_size == group]
+
+
+def split_accumulation(avg_grad_every_n: int, world: int) -> int:
+    """Micro-batches each rank runs per optimizer step so that world * local == avg_grad_every_n."""
+    if avg_grad_every_n % world != 0:
+        raise ValueError(f"avg_grad_every_n={avg_grad_every_n} must be a multiple of the world size {world} "
+                         f"for the data-parallel update to equal the single-process one")
+    return avg_grad_every_n // world
+
+
+class FlatGrads:
+    """All trainable gradients as views of one flat fp32 buffer."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGrads: no trainable parameters")
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        # 16-byte aligned slices keep the vector paths of the SGD kernel
+        offs, cur = [], 0
+        for p in self.params:
+            offs.append(cur)
+            cur += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(cur, dtype=torch.float32, device=dev)
+        self.numel = total
+        for p, o in zip(self.params, offs):
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+
+    def zero(self) -> None:
+        self.flat.zero_()
+
+    def all_reduce(self, async_op: bool = False):
+        """SUM over ranks (no-op in a single process)."""
+        if world_size() == 1:
+            return None
+        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)

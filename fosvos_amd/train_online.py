@@ -1,0 +1,189 @@
+"""One-shot online fine-tuning (reference: src/train_online.py).
+
+Same entry points - ``train_and_test(net_provider, seq_name, settings)`` and ``_train(...)`` with the
+reference's positional arguments - and the same loop semantics (src/train_online.py:70-107): forward,
+class-balanced BCE on ``outputs[-1]`` with ``size_average=False``, ``loss /= avg_grad_every_n``,
+backward, ``optimizer.step(); optimizer.zero_grad()`` every ``avg_grad_every_n``-th iteration.  The
+arithmetic runs on the HIP kernels; the loss is accumulated on the device and only read back at the
+reference's logging points, so the loop does not synchronise every iteration.
+
+Run:  python train_online.py --synthetic --n-epochs 100        (one GPU)
+      torchrun --nproc-per-node 8 train_online.py --synthetic --data-parallel --avg-grad-every-n 8
+"""
+import sys
+import timeit
+from pathlib import Path
+from typing import Optional
+
+import torch
+from torch import optim
+
+from config.mypath import Path as P
+from layers.osvos_layers import class_balanced_cross_entropy_loss
+from util import gpu_handler, io_helper, experiment_helper, args_helper
+from util.logger import get_logger
+from util.network_provider import NetworkProvider, provider_mapping
+from util.settings import OnlineSettings
+import parallel
+
+log = get_logger(__file__)
+
+# run-wide locations; the reference keeps these as module globals set in __main__
+save_dir_models = Path('models')
+save_dir_results = Path('results')
+path_stem = 'vgg16/online'
+db_root_dir = None
+synthetic_size = None       # (H, W) when --synthetic
+data_parallel = False
+
+sequences_val = ['blackswan', 'bmx-trees', 'breakdance', 'camel', 'car-roundabout', 'car-shadow', 'cows',
+                 'dance-twirl', 'dog', 'drift-chicane', 'drift-straight', 'goat', 'horsejump-high', 'kite-surf',
+                 'libby', 'motocross-jump', 'paragliding-launch', 'parkour', 'scooter-black', 'soapbox']
+
+
+def train_and_test(net_provider: NetworkProvider, seq_name: str, settings: OnlineSettings) -> None:
+    io_helper.write_settings(save_dir_models, net_provider.name, settings, variant_offline=settings.variant_offline,
+                             variant_online=settings.variant_online)
+    summary_writer = _get_summary_writer(path_stem)
+
+    if settings.is_training:
+        net_provider.load_network_train()
+        data_loader = io_helper.get_data_loader_train(db_root_dir, settings.batch_size_train, seq_name,
+                                                      synthetic=synthetic_size)
+        optimizer = net_provider.get_optimizer()
+        _train(net_provider, data_loader, optimizer, summary_writer, seq_name, settings.start_epoch, settings.n_epochs,
+               settings.avg_grad_every_n, settings.snapshot_every_n)
+
+    if settings.is_testing:
+        if not settings.is_training:
+            net_provider.load_network_test(sequence=seq_name)
+        data_loader = io_helper.get_data_loader_test(db_root_dir, settings.batch_size_test, seq_name,
+                                                     synthetic=synthetic_size)
+        if settings.variant_offline is None:
+            save_dir = save_dir_results / net_provider.name / 'online'
+        else:
+            save_dir = (save_dir_results / net_provider.name / str(settings.variant_offline) /
+                        str(settings.variant_online))
+        experiment_helper.test(net_provider, data_loader, save_dir, settings.is_visualizing_results,
+                               settings.eval_speeds, seq_name=seq_name)
+
+
+def _get_summary_writer(seq_name: str):
+    return io_helper.get_summary_writer(Path('tensorboard') / path_stem)
+
+
+def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summary_writer, seq_name: str,
+           start_epoch: int, n_epochs: int, avg_grad_every_n: int, snapshot_every_n: int) -> dict:
+    log.info('Start of Online Training, sequence: ' + seq_name)
+    net = net_provider.network
+    world = parallel.world_size() if data_parallel else 1
+    local_accum = parallel.split_accumulation(avg_grad_every_n, world)
+    flat = parallel.FlatGrads(net.parameters()) if world > 1 else None
+
+    n_samples = len(dataloader)
+    loss_tr = []
+    counter_gradient = 0
+    log_every = max(n_epochs // 20, 1)  # the reference divides by n_epochs // 20, which is 0 below 20 epochs
+    device = next(net.parameters()).device
+    running_loss_tr = torch.zeros((), device=device)
+
+    time_all_start = timeit.default_timer()
+    n_iters = 0
+    for epoch in range(start_epoch, n_epochs):
+        loss_epoch = torch.zeros((), device=device)
+        for minibatch_index, minibatch in enumerate(dataloader):
+            inputs, gts = minibatch['image'], minibatch['gt']
+            inputs, gts = gpu_handler.cast_cuda_if_possible([inputs, gts])
+
+            outputs = net.forward(inputs)
+
+            loss = class_balanced_cross_entropy_loss(outputs[-1], gts, size_average=False)
+            running_loss_tr += loss.detach()
+
+            if epoch % log_every == log_every - 1:
+                value = float(running_loss_tr) / n_samples  # the only device->host sync of the loop
+                loss_tr.append(value)
+                running_loss_tr.zero_()
+                log.info('[Epoch {0}: {1}, numImages: {2}]'.format(seq_name, epoch + 1, minibatch_index + 1))
+                log.info('Loss {0}: {1}'.format(seq_name, value))
+                summary_writer.add_scalar('data/total_loss_epoch', value, epoch)
+
+            loss = loss / avg_grad_every_n
+            loss.backward()
+            loss_epoch += loss.detach()
+            counter_gradient += 1
+            n_iters += 1
+
+            if counter_gradient % local_accum == 0:
+                if flat is not None:
+                    flat.all_reduce()
+                optimizer.step()
+                if flat is not None:
+                    flat.zero()
+                else:
+                    optimizer.zero_grad()
+                counter_gradient = 0
+
+        if (epoch % snapshot_every_n) == snapshot_every_n - 1 and parallel.rank() == 0:
+            net_provider.save_model(epoch, sequence=seq_name)
+
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    time_for_all = timeit.default_timer() - time_all_start
+    n_images = len(dataloader)
+    log.info('Train {0}: total time {1} sec'.format(seq_name, str(time_for_all)))
+    log.info('Train {0}: {1} images'.format(seq_name, str(n_images)))
+    log.info('Train {0}: time per sample {1} sec'.format(seq_name, str(time_for_all / max(n_images, 1))))
+    return {'loss': loss_tr, 'seconds': time_for_all, 'iterations': n_iters}
+
+
+def main(argv=None):
+    global db_root_dir, synthetic_size, data_parallel, save_dir_models, save_dir_results
+    args = args_helper.parse_args(is_online=True, argv=argv)
+    if args.network != 'vgg16':
+        raise SystemExit('only --network vgg16 is implemented on the HIP path (ResNet family: SURVEY.md §8 f4)')
+    data_parallel = bool(args.data_parallel) and parallel.init_distributed()
+    gpu_handler.select_gpu(args.gpu_id)
+
+    db_root_dir = P.db_root_dir()
+    synthetic_size = (args.height, args.width) if args.synthetic else None
+    save_dir_models.mkdir(parents=True, exist_ok=True)
+    save_dir_results.mkdir(parents=True, exist_ok=True)
+    path_input_model = Path(args.parent_model) if args.parent_model else save_dir_models / 'vgg16_epoch-239.pth'
+    path_output_model_base = save_dir_models / path_stem
+    path_output_model_base.mkdir(parents=True, exist_ok=True)
+
+    settings = OnlineSettings(is_training=args.is_training, is_testing=args.is_testing, start_epoch=0,
+                              n_epochs=args.n_epochs or 10000, avg_grad_every_n=args.avg_grad_every_n or 5,
+                              snapshot_every_n=args.n_epochs or 10000, is_testing_while_training=False, test_every_n=5,
+                              batch_size_train=1, batch_size_test=1, is_visualizing_network=False,
+                              is_visualizing_results=False, offline_epoch=240, variant_offline=args.variant_offline,
+                              variant_online=args.variant_online, eval_speeds=args.eval_speeds)
+
+    provider_class = provider_mapping[('online', args.network)]
+    net_provider = provider_class(name=args.network, save_dir=(path_input_model, path_output_model_base),
+                                  settings=settings, variant_offline=args.variant_offline,
+                                  variant_online=args.variant_online)
+    if args.synthetic and not path_input_model.exists():
+        # no parent checkpoint offline: write a seeded random-init one so the load path is exercised
+        from networks.osvos_vgg import OSVOS_VGG
+        torch.manual_seed(0)
+        if parallel.rank() == 0:
+            path_input_model.parent.mkdir(parents=True, exist_ok=True)
+            torch.save(OSVOS_VGG(pretrained=0).state_dict(), str(path_input_model))
+        if data_parallel:
+            torch.distributed.barrier()
+
+    if args.sequence_name is None:
+        # replicas: the reference's -sg/-sgs sharding; under torchrun without --data-parallel the ranks shard
+        group, group_size = args.sequence_group, args.sequence_group_size
+        if group is None and not data_parallel and parallel.init_distributed():
+            group, group_size = parallel.rank(), parallel.world_size()
+        sequences = parallel.shard_sequences(sequences_val, group, group_size)
+        [train_and_test(net_provider, s, settings) for s in sequences]
+    else:
+        train_and_test(net_provider, args.sequence_name, settings)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,190 @@
+/*
+ * fosvos_hip.h - C ABI of libfosvos_hip.so: hand-written HIP (gfx950 / MI355X) kernels for the
+ * OSVOS-VGG fine-tune hot path of klausondrag/FOSVOS.
+ *
+ * The reference has no FFI layer: its hot path runs through stock torch.nn modules
+ * (src/networks/osvos_vgg.py:42-48,56,90-93 and src/layers/osvos_layers.py:17-54), i.e. the
+ * arithmetic lives in third-party torch/cuDNN.  Each entry point below replaces one of those
+ * call sites; the citation after "replaces:" names it (paths relative to the reference root).
+ * The Python host (fosvos_amd/) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
+ *   - the library allocates nothing persistent: outputs and workspaces belong to the caller,
+ *     `*_workspace_bytes` tells how much scratch an op needs;
+ *   - every call is asynchronous on `stream` (a hipStream_t) of `device`; no implicit sync;
+ *   - return 0 on success, a negative FOSVOS_E_* code otherwise; fosvos_last_error() gives a
+ *     thread-local message.  Nothing aborts or throws across the ABI;
+ *   - re-entrant; the device is selected on every call (autograd runs backward on another thread).
+ *
+ * Tensor layouts
+ *   frame   fp32 NCHW [N,3,H,W]                  (the reference's input layout)
+ *   act     bf16 NHWC [N,H,W,C], C % 32 == 0     (internal feature maps, uint16_t storage)
+ *   side    fp32 NHWC [N,h,w,16]                 (side_prep outputs)
+ *   logit   fp32 [N,1,H,W]
+ *   weight  fp32 OIHW [Co,Ci,3,3] masters as in the reference state_dict; bf16 packed copies
+ *           [Ci/32][9][4][Co][8] for the MFMA kernels (see fosvos_pack_conv3x3_weights).
+ */
+#ifndef FOSVOS_HIP_H
+#define FOSVOS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FOSVOS_ABI_VERSION 1
+
+#define FOSVOS_OK 0
+#define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
+#define FOSVOS_E_ARG (-2)       /* null pointer / bad flag                       */
+#define FOSVOS_E_WORKSPACE (-3) /* caller workspace too small                    */
+#define FOSVOS_E_HIP (-4)       /* HIP runtime error (message has the hip text)  */
+
+/* conv epilogue flags */
+#define FOSVOS_CONV_RELU 1u    /* y = max(y, 0)                                   */
+#define FOSVOS_CONV_OUT_F32 2u /* store fp32 NHWC instead of bf16 NHWC            */
+
+int fosvos_abi_version(void);
+const char *fosvos_last_error(void);
+/* Name of the gfx target the code object was built for ("gfx950"). */
+const char *fosvos_build_arch(void);
+
+/* ---- layout helpers (test/debug plumbing and the model's input/feature export) -------------- */
+/* fp32 NCHW -> bf16 NHWC, channels zero-padded from C to Cpad (Cpad % 8 == 0, Cpad >= C). */
+int fosvos_nchw_f32_to_nhwc_bf16(const float *src, uint16_t *dst, int N, int C, int H, int W, int Cpad,
+                                 int device, void *stream);
+/* bf16 NHWC (first C of Cpad channels) -> fp32 NCHW. */
+int fosvos_nhwc_bf16_to_nchw_f32(const uint16_t *src, float *dst, int N, int C, int H, int W, int Cpad,
+                                 int device, void *stream);
+/* fp32 NHWC <-> fp32 NCHW */
+int fosvos_nhwc_f32_to_nchw_f32(const float *src, float *dst, int N, int C, int H, int W, int device, void *stream);
+int fosvos_nchw_f32_to_nhwc_f32(const float *src, float *dst, int N, int C, int H, int W, int device, void *stream);
+
+/* ---- weight packing ---------------------------------------------------------------------------
+ * fp32 OIHW master -> the two bf16 images the MFMA kernels read.
+ *   w_fwd  [ceil(Ci/32)][9][4][Co_pad][8] : element (co,ci,tap) of the forward conv
+ *   w_dgrad[ceil(Co/32)][9][4][Ci_pad][8] : element (ci,co,8-tap), i.e. the transposed, 180-degree
+ *                                           rotated filter, so dgrad runs as a forward conv
+ * Channel counts are zero-padded to multiples of 32 on the contraction side and to 16 on the
+ * output side (Co_pad = roundup(Co,16), Ci_pad = roundup(Ci,16)).  Either output may be NULL.
+ * replaces: the weight operand of nn.Conv2d (src/networks/osvos_vgg.py:42,92). */
+int fosvos_pack_conv3x3_weights(const float *w_oihw, int Co, int Ci, uint16_t *w_fwd, uint16_t *w_dgrad,
+                                int device, void *stream);
+size_t fosvos_packed_weight_elems(int out_ch, int in_ch); /* elements of one packed image */
+
+/* ---- first layer: conv1_1 (Ci = 3) straight from the fp32 NCHW frame --------------------------
+ * y[N,H,W,Co] bf16 = relu(conv3x3(frame, w, pad 1) + b), fp32 VALU arithmetic (K = 27).
+ * replaces: stages[0][0..1] = Conv2d(3,64,3,pad=1)+ReLU (src/networks/osvos_vgg.py:92-93). */
+int fosvos_conv3x3_first_fwd(const float *frame, const float *w_oihw, const float *bias, uint16_t *y, int N, int H,
+                             int W, int Co, int device, void *stream);
+/* dw[Co,3,3,3], db[Co] (fp32, overwritten) from the frame and dy[N,H,W,Co] bf16.  No dgrad: the
+ * image needs no gradient.  workspace: fosvos_conv3x3_first_wgrad_workspace_bytes. */
+int fosvos_conv3x3_first_wgrad(const float *frame, const uint16_t *dy, float *dw_oihw, float *dbias, int N, int H,
+                               int W, int Co, void *workspace, size_t workspace_bytes, int device, void *stream);
+size_t fosvos_conv3x3_first_wgrad_workspace_bytes(int N, int H, int W, int Co);
+
+/* ---- 3x3 conv, pad 1, stride 1, as an implicit GEMM on bf16 MFMA with fp32 accumulation -------
+ * y[N,H,W,Co] = epilogue( sum_{tap,ci} x[N,H+dy,W+dx,ci] * w[co,ci,tap] + bias[co] )
+ *   x        bf16 NHWC with Ci_pad = roundup(Ci,32) channels
+ *   w_packed the matching image from fosvos_pack_conv3x3_weights
+ *   bias     fp32 [Co] or NULL
+ *   y        bf16 NHWC with Co channels (Co % 16 == 0), or fp32 NHWC when FOSVOS_CONV_OUT_F32
+ * replaces: Conv2d(3x3,pad=1)[+ReLU] in stages[*] and side_prep[*]
+ *           (src/networks/osvos_vgg.py:42,92-93). */
+int fosvos_conv3x3_fwd(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int N, int H, int W,
+                       int Ci, int Co, unsigned flags, void *workspace, size_t workspace_bytes, int device,
+                       void *stream);
+/* Scratch for fwd/dgrad with `in_ch` contraction and `out_ch` output channels (split-K partial
+ * slabs for layers whose pixel count alone cannot fill 256 CUs; 0 when none is needed). */
+size_t fosvos_conv3x3_workspace_bytes(int N, int H, int W, int in_ch, int out_ch);
+/* dx = mask( dgrad(dy) ) + addend:  the same kernel run on the rotated/transposed filter image.
+ *   dy       bf16 NHWC, Co_pad = roundup(Co,32) channels (Co = the forward op's OUTPUT channels)
+ *   relu_src bf16 NHWC [N,H,W,Ci] or NULL: where relu_src <= 0 the computed gradient is zeroed
+ *            (ReLU backward of the layer that produced x, fused)
+ *   addend   bf16 NHWC [N,H,W,Ci] or NULL: added after masking (gradient arriving at the same
+ *            tensor through another consumer); may alias dx
+ * replaces: autograd's conv backward-data for the same modules. */
+int fosvos_conv3x3_dgrad(const uint16_t *dy, const uint16_t *w_dgrad_packed, const uint16_t *relu_src,
+                         const uint16_t *addend, uint16_t *dx, int N, int H, int W, int Ci, int Co, void *workspace,
+                         size_t workspace_bytes, int device, void *stream);
+/* dw[Co,Ci,3,3] (fp32 OIHW) and db[Co] (may be NULL) from x[N,H,W,Ci] and dy[N,H,W,Co_pad] (bf16).
+ * Deterministic: split partial sums are written as slabs to the workspace and reduced in a fixed
+ * order.  accumulate != 0 adds into dw/db instead of overwriting.
+ * replaces: autograd's conv backward-weight/bias. */
+int fosvos_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, float *dw_oihw, float *dbias, int N, int H, int W,
+                         int Ci, int Co, int accumulate, void *workspace, size_t workspace_bytes, int device,
+                         void *stream);
+size_t fosvos_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
+
+/* ---- 2x2 stride-2 ceil-mode max pool on bf16 NHWC ---------------------------------------------
+ * y[N,ceil(H/2),ceil(W/2),C]; ragged last row/column windows hold 2 or 1 elements.
+ * replaces: MaxPool2d(2,2,ceil_mode=True) (src/networks/osvos_vgg.py:90). */
+int fosvos_maxpool2x2_ceil_fwd(const uint16_t *x, uint16_t *y, int N, int H, int W, int C, int device, void *stream);
+/* dx[N,H,W,C]: dy routed to the first maximum of each window in (row, column) scan order, zero
+ * elsewhere; relu_mask != 0 also zeroes it where x <= 0 (ReLU backward of the producer, fused). */
+int fosvos_maxpool2x2_ceil_bwd(const uint16_t *x, const uint16_t *dy, uint16_t *dx, int N, int H, int W, int C,
+                               int relu_mask, int device, void *stream);
+
+/* ---- fused side-output head -------------------------------------------------------------------
+ * For the four scales s (stride f = 2,4,8,16; deconv kernel k = 2f) with side[s] fp32 NHWC
+ * [N,hs[s],ws[s],16]:
+ *   fused[n,0,Y,X]   = fuse_b + sum_s sum_c fuse_w[16 s + c] * crop(up_s(side[s]))[c,Y,X]
+ *   side_out[s][..]  = crop(up1_s(dsn_b[s] + sum_c dsn_w[s][c] * side[s][c]))        (optional)
+ * up_s is the transposed conv with the DIAGONAL of upscale[s].weight, passed as filt[s] =
+ * [16][k][k] fp32 (one k x k filter per channel); up1_s uses filt1[s] = [k][k].  crop is the
+ * reference's centre crop (floor(d/2) leading pixels removed).
+ * replaces: upscale[s], upscale_[s], score_dsn[s], center_crop, torch.cat and fuse
+ *           (src/networks/osvos_vgg.py:69-82, src/layers/osvos_layers.py:47-54). */
+int fosvos_head_fwd(const float *const side[4], const int hs[4], const int ws[4], const float *const filt[4],
+                    const float *const filt1[4], const float *dsn_w /*[4][16]*/, const float *dsn_b /*[4]*/,
+                    const float *fuse_w /*[64]*/, const float *fuse_b /*[1]*/, float *fused,
+                    float *const side_out[4] /* all NULL or all set */, int N, int H, int W, int device, void *stream);
+/* Backward of the above.
+ *   d_fused [N,1,H,W] fp32 or NULL;  d_side_out[s] [N,1,H,W] fp32 or NULL (all or none)
+ *   d_side[s]   bf16 NHWC [N,hs,ws,32]: channels 0..15 = gradient wrt side[s], 16..31 = 0 (the
+ *               padded image the side_prep dgrad/wgrad MFMA kernels read)
+ *   d_fuse_w[64], d_fuse_b[1], d_dsn_w[4*16], d_dsn_b[4]: fp32, overwritten (d_dsn_* may be NULL
+ *               when d_side_out is NULL).
+ * workspace: fosvos_head_bwd_workspace_bytes. */
+int fosvos_head_bwd(const float *const side[4], const int hs[4], const int ws[4], const float *const filt[4],
+                    const float *const filt1[4], const float *dsn_w, const float *fuse_w, const float *d_fused,
+                    const float *const d_side_out[4], uint16_t *const d_side[4], float *d_fuse_w, float *d_fuse_b,
+                    float *d_dsn_w, float *d_dsn_b, int N, int H, int W, void *workspace, size_t workspace_bytes,
+                    int device, void *stream);
+size_t fosvos_head_bwd_workspace_bytes(int N, int H, int W);
+
+/* ---- class-balanced BCE-with-logits, loss and gradient in one call ----------------------------
+ * y_i = label_i >= 0.5; Np = #y, Nn = numel - Np;
+ * loss = (Nn/numel) * sum_{y=1} l_i + (Np/numel) * sum_{y=0} l_i,  l_i = max(x,0) - x y + log(1+exp(-|x|))
+ * [divided by numel when size_average]; grad_i = scale * w_i * (sigmoid(x_i) - y_i) with the same
+ * weights (and the 1/numel factor when size_average).  Reductions run over the whole batch tensor
+ * and are deterministic (fixed-order fp64 partials).  loss_out: one fp32 on the device.
+ * grad may be NULL.  workspace: fosvos_cbce_workspace_bytes.
+ * replaces: class_balanced_cross_entropy_loss + its autograd (src/layers/osvos_layers.py:17-44). */
+int fosvos_cbce_loss(const float *logits, const float *label, int64_t numel, int size_average, float grad_scale,
+                     float *loss_out, float *grad, void *workspace, size_t workspace_bytes, int device,
+                     void *stream);
+size_t fosvos_cbce_workspace_bytes(int64_t numel);
+
+/* ---- SGD with momentum, torch.optim.SGD semantics, many tensors per launch --------------------
+ * For tensor t with n[t] elements: g = grad + wd[t]*p; buf = first_step ? g : momentum*buf + g;
+ * p -= lr[t]*buf.  `table` is a DEVICE array of n_tensors fosvos_sgd_entry records.
+ * replaces: optim.SGD.step for the groups of src/util/network_provider.py:144-159 / 98-125. */
+typedef struct fosvos_sgd_entry {
+    float *param;
+    const float *grad;
+    float *momentum_buf;
+    int64_t numel;
+    float lr;
+    float weight_decay;
+} fosvos_sgd_entry;
+int fosvos_sgd_momentum_step(const fosvos_sgd_entry *table, int n_tensors, int64_t max_numel, float momentum,
+                             int first_step, int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOSVOS_HIP_H */

@@ -326,10 +326,12 @@ def offline_loop(sd: Dict[str, torch.Tensor], images: Sequence[torch.Tensor], gt
 # Synthetic inputs: uniform BGR frame minus the dataset mean, elliptical mask
 # ----------------------------------------------------------------------------------------------
 def synthetic_frame(n: int, h: int, w: int, seed: int = 1234) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Uniform-noise BGR frame with a brighter, lower-contrast elliptical object (~10 % of the pixels),
+    minus the dataset mean; gt = the ellipse.  The object is photometrically distinct so that a network
+    can actually learn it (needed for the confident-logit IoU tests)."""
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
-    img = torch.rand((n, 3, h, w), generator=g) * 255.0
-    img = img - torch.tensor(BGR_MEAN, dtype=torch.float32).view(1, 3, 1, 1)
+    noise = torch.rand((n, 3, h, w), generator=g)
     yy = torch.arange(h, dtype=torch.float32).view(h, 1)
     xx = torch.arange(w, dtype=torch.float32).view(1, w)
     gt = torch.zeros((n, 1, h, w), dtype=torch.float32)
@@ -337,4 +339,6 @@ def synthetic_frame(n: int, h: int, w: int, seed: int = 1234) -> Tuple[torch.Ten
         cy, cx = h * (0.45 + 0.05 * i), w * (0.5 - 0.03 * i)
         ry, rx = h * 0.2, w * 0.16  # pi*0.2*0.16 ~= 10 % foreground
         gt[i, 0] = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0).float()
+    img = gt * (150.0 + 100.0 * noise) + (1.0 - gt) * (150.0 * noise)
+    img = img - torch.tensor(BGR_MEAN, dtype=torch.float32).view(1, 3, 1, 1)
     return img, gt

@@ -1,0 +1,256 @@
+"""Whole-path parity on a real MI355X: the drop-in OSVOS_VGG module, loss, optimizer and the online /
+offline loops against (a) the golden fixtures the reference produced and (b) the CPU oracle on the same
+seeded inputs.  bf16 activations + fp32 accumulation vs an fp32 reference: tolerances are stated per test.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import osvos_ref as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fosvos_amd"))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# bf16 activations through 13 conv layers: measured error is ~0.5 % of the logit range; gate at 2 %
+LOGIT_TOL = 2e-2
+# per-tensor gradient agreement with the fp32 oracle
+GRAD_COS = 0.995
+GRAD_REL_L2 = 8e-2
+
+
+def make_net(seed, scheme="kaiming"):
+    from networks.osvos_vgg import OSVOS_VGG
+    net = OSVOS_VGG(pretrained=0)
+    sd = O.make_state_dict(seed, scheme)
+    net.load_state_dict(sd)
+    return net.to(DEV), sd
+
+
+def rel_to_max(a, ref):
+    return (a - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+
+
+def test_module_surface():
+    net, sd = make_net(1)
+    assert list(net.state_dict().keys()) == list(O.state_dict_spec().keys())
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == O.state_dict_spec()[k]
+    for attr in ("stages", "side_prep", "score_dsn", "upscale", "upscale_", "fuse"):
+        assert hasattr(net, attr)
+    assert sum(p.numel() for p in net.parameters()) == 15267157
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 8, 8))  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("tag", ["s", "r"])
+def test_forward_vs_reference_golden(golden, tag):
+    k = golden("net.npz")
+    n, h, w = (int(v) for v in k[f"{tag}_shape"])
+    net, sd = make_net(int(k[f"{tag}_seed"]))
+    x, gt = O.synthetic_frame(n, h, w, seed=int(k[f"{tag}_frame_seed"]))
+    with torch.no_grad():
+        outs = net(x.to(DEV))
+    assert len(outs) == 5
+    for i, o in enumerate(outs):
+        ref = torch.from_numpy(k[f"{tag}_out{i}"])
+        assert tuple(o.shape) == tuple(ref.shape)
+        err = rel_to_max(o.cpu(), ref)
+        assert err < LOGIT_TOL, f"output {i}: {err:.3e} of the logit range"
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    for i, o in enumerate(outs):
+        l = cbce(o, gt.to(DEV), size_average=False).item()
+        assert abs(l - float(k[f"{tag}_loss{i}"])) <= 2e-2 * abs(float(k[f"{tag}_loss{i}"]))
+
+
+def _oracle_grads(sd, x, gt, objective):
+    params = O.leaf_params(sd)
+    outs = O.forward(params, x)
+    losses = [O.cbce_loss(o, gt, size_average=False) for o in outs]
+    if objective == "online":
+        total = losses[-1]
+    else:
+        total = (1 - 60 / 240) * sum(losses[:-1]) + losses[-1]
+    grads = torch.autograd.grad(total, list(params.values()), allow_unused=True)
+    return dict(zip(params.keys(), grads)), [l.item() for l in losses]
+
+
+@pytest.mark.parametrize("objective", ["online", "offline"])
+@pytest.mark.parametrize("shape,seed", [((1, 48, 86), 3), ((2, 61, 107), 4)])
+def test_backward_vs_oracle(shape, seed, objective):
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    n, h, w = shape
+    net, sd = make_net(seed)
+    x, gt = O.synthetic_frame(n, h, w, seed=100 + seed)
+    ref_grads, ref_losses = _oracle_grads(sd, x, gt, objective)
+    outs = net(x.to(DEV))
+    losses = [cbce(o, gt.to(DEV), size_average=False) for o in outs]
+    total = losses[-1] if objective == "online" else (1 - 60 / 240) * sum(losses[:-1]) + losses[-1]
+    total.backward()
+    report = []
+    for name, p in net.named_parameters():
+        ref = ref_grads[name]
+        if name.startswith("upscale"):
+            assert p.grad is None  # frozen by recipe (lr 0): no gradient is produced
+            continue
+        if ref is None:
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None, name
+        g = p.grad.detach().cpu().double().reshape(-1)
+        r = ref.double().reshape(-1)
+        cos = float((g @ r) / (g.norm() * r.norm() + 1e-300))
+        rel = float((g - r).norm() / (r.norm() + 1e-300))
+        report.append((name, cos, rel))
+    bad = [(nm, c, r) for nm, c, r in report if c < GRAD_COS or r > GRAD_REL_L2]
+    assert not bad, "gradient mismatch: " + "; ".join(f"{nm} cos={c:.5f} rel={r:.3e}" for nm, c, r in bad)
+
+
+def test_online_loop_vs_golden(golden):
+    """10 iterations of the online loop (step every 5, two alternating frame sizes) through the drop-in
+    _train body, against the trace the reference produced."""
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    from util.network_provider import VGGOnlineProvider
+    k = golden("loops.npz")
+    for tag, lr in (("lr1e-8", 1e-8), ("lr1e-6", 1e-6)):
+        net, sd = make_net(6)
+        prov = VGGOnlineProvider.__new__(VGGOnlineProvider)
+        prov.network = net
+        opt = prov.get_optimizer(learning_rate=lr)
+        frames = [O.synthetic_frame(1, 48, 86, seed=21), O.synthetic_frame(1, 40, 70, seed=22)]
+        trace, counter = [], 0
+        for it in range(10):
+            x, gt = frames[it % 2]
+            outs = net.forward(x.to(DEV))
+            loss = cbce(outs[-1], gt.to(DEV), size_average=False)
+            trace.append(loss.item())
+            (loss / 5).backward()
+            counter += 1
+            if counter % 5 == 0:
+                opt.step()
+                opt.zero_grad()
+                counter = 0
+        np.testing.assert_allclose(trace, k[f"online_{tag}_loss"], rtol=2e-2)
+        # the weight update itself: compare the applied delta of a few tensors with the reference's
+        for name in ("fuse.weight", "fuse.bias", "stages.4.5.bias", "side_prep.3.weight", "stages.0.0.weight"):
+            p = dict(net.named_parameters())[name].detach().cpu().double().reshape(-1)
+            d = p - sd[name].double().reshape(-1)
+            idx = torch.from_numpy(k[f"online_{tag}_delta_{name}_i"])
+            ref = torch.from_numpy(k[f"online_{tag}_delta_{name}_s"]).double()
+            got = d[idx]
+            scale = ref.abs().max().item()
+            if scale == 0:
+                continue
+            # fp32 masters: an update of 1e-8 * grad sits near the fp32 resolution of the weight itself
+            ulp = float(np.spacing(np.float32(sd[name].abs().max().item())))
+            assert (got - ref).abs().max().item() <= 8e-2 * scale + 2 * ulp, name
+        for name, p in net.named_parameters():  # frozen / unoptimised tensors do not move
+            if name.startswith(("upscale", "score_dsn")):
+                assert torch.equal(p.detach().cpu(), sd[name])
+
+
+def test_offline_loop_vs_golden(golden):
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    from util.network_provider import VGGOfflineProvider
+    k = golden("loops.npz")
+    net, sd = make_net(8)
+    prov = VGGOfflineProvider.__new__(VGGOfflineProvider)
+    prov.network = net
+    opt = prov.get_optimizer(learning_rate=1e-6)
+    x, gt = O.synthetic_frame(2, 33, 47, seed=23)
+    trace, counter = [], 0
+    for it in range(4):
+        outs = net.forward(x.to(DEV))
+        ls = [cbce(o, gt.to(DEV), size_average=False) for o in outs]
+        trace.append([l.item() for l in ls])
+        loss = (1 - 60 / 240) * sum(ls[:-1]) + ls[-1]
+        (loss / 2).backward()
+        counter += 1
+        if counter % 2 == 0:
+            opt.step()
+            opt.zero_grad()
+            counter = 0
+    np.testing.assert_allclose(np.array(trace), k["offline_loss"], rtol=3e-2)
+
+
+def test_e2e_480x854_vs_reference(golden):
+    """BASELINE-size frame: fused logits vs the reference's stored map; mask agreement outside an
+    epsilon band around 0."""
+    k = golden("e2e_480x854.npz")
+    net, sd = make_net(int(k["seed"]))
+    x, gt = O.synthetic_frame(1, 480, 854, seed=int(k["frame_seed"]))
+    with torch.no_grad():
+        outs = net(x.to(DEV))
+    fused = outs[-1][0, 0].cpu()
+    ref = torch.from_numpy(k["logits_f16"]).float()
+    amax = float(k["logits_absmax"])
+    err = (fused - ref).abs().max().item() / amax
+    assert err < LOGIT_TOL, f"fused logits off by {err:.3e} of the range"
+    ref_mask = torch.from_numpy(np.unpackbits(k["mask_bits"])[: 480 * 854].reshape(480, 854)).bool()
+    band = ref.abs() > LOGIT_TOL * amax
+    assert torch.equal((fused >= 0)[band], ref_mask[band])
+    for i in range(4):
+        idx = torch.from_numpy(k[f"side{i}_i"])
+        smp = torch.from_numpy(k[f"side{i}_s"])
+        got = outs[i].cpu().reshape(-1)[idx]
+        assert (got - smp).abs().max().item() <= LOGIT_TOL * float(k["side_absmax"][i])
+
+
+def test_mask_iou_after_finetune():
+    """Per-pixel mask IoU vs the oracle on a network with CONFIDENT logits (as a trained OSVOS has):
+    fit the synthetic object on the HIP path for a few hundred steps, then compare HIP and oracle
+    forward passes of the SAME weights at 854x480.  IoU within 1e-3 (north_star)."""
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    net, _ = make_net(11)
+    x, gt = O.synthetic_frame(1, 240, 427, seed=77)
+    xd, gd = x.to(DEV), gt.to(DEV)
+    opt = torch.optim.Adam([p for n_, p in net.named_parameters() if not n_.startswith("upscale")], lr=2e-4)
+    first = None
+    for it in range(200):
+        opt.zero_grad()
+        loss = cbce(net(xd)[-1], gd, size_average=True)
+        loss.backward()
+        opt.step()
+        if it == 0:
+            first = loss.item()
+    last = loss.item()
+    assert last < 0.5 * first, f"fine-tuning on the HIP path does not reduce the loss ({first} -> {last})"
+    X, GT = O.synthetic_frame(1, 480, 854, seed=78)
+    with torch.no_grad():
+        hip = net(X.to(DEV))[-1].cpu()
+        sd = {k_: v.detach().cpu() for k_, v in net.state_dict().items()}
+        ref = O.forward(sd, X)[-1]
+    m_hip, m_ref = O.logits_to_mask(hip), O.logits_to_mask(ref)
+    iou = O.mask_iou(m_hip, m_ref)
+    iou_gt_hip, iou_gt_ref = O.mask_iou(m_hip, GT > 0.5), O.mask_iou(m_ref, GT > 0.5)
+    print(f"IoU(hip, oracle)={iou:.5f}  IoU(hip, gt)={iou_gt_hip:.4f}  IoU(oracle, gt)={iou_gt_ref:.4f}")
+    assert iou_gt_ref > 0.5, "the fitted network does not segment the object; the IoU check would be vacuous"
+    assert abs(iou - 1.0) <= 1e-3
+    assert abs(iou_gt_hip - iou_gt_ref) <= 1e-3
+    assert rel_to_max(hip, ref) < LOGIT_TOL
+
+
+def test_train_online_entry_point(tmp_path, monkeypatch):
+    """The drop-in script surface: train_and_test / _train on a synthetic sequence, 10 epochs."""
+    monkeypatch.chdir(tmp_path)
+    import train_online
+    from networks.osvos_vgg import OSVOS_VGG
+    from util.network_provider import provider_mapping
+    from util.settings import OnlineSettings
+    torch.manual_seed(0)
+    parent = tmp_path / "parent.pth"
+    torch.save(OSVOS_VGG(pretrained=0).state_dict(), str(parent))
+    train_online.synthetic_size = (96, 160)
+    settings = OnlineSettings(is_training=True, is_testing=True, start_epoch=0, n_epochs=10, avg_grad_every_n=5,
+                              snapshot_every_n=10, is_testing_while_training=False, test_every_n=5, batch_size_train=1,
+                              batch_size_test=1, is_visualizing_network=False, is_visualizing_results=False,
+                              variant_offline=None, eval_speeds=False, offline_epoch=240, variant_online=None)
+    prov = provider_mapping[("online", "vgg16")](name="vgg16", save_dir=(parent, tmp_path / "out"), settings=settings)
+    train_online.train_and_test(prov, "synthetic", settings)
+    assert (tmp_path / "out" / "vgg16_synthetic_epoch-9.pth").exists()
+    assert len(list((tmp_path / "results" / "vgg16" / "online" / "synthetic").glob("*.png"))) == 4

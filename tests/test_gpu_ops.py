@@ -1,0 +1,399 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against the CPU oracle (plain torch
+fp32 on the same, identically rounded inputs).  Run with ``pytest -m gpu``.
+
+Tolerances (stated per test):
+  * bf16 outputs: one bf16 rounding of an fp32-accumulated value: |err| <= 2^-8 |ref| + fp32 noise
+  * fp32 outputs: fp32 accumulation-order noise only
+  * integer/index work (pool selection and routing): exact
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import osvos_ref as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fosvos_amd"))
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from fosvos_hip import ops as _ops
+    return _ops
+
+
+def bf(t):  # round to bf16, keep fp32 container
+    return t.to(torch.bfloat16).float()
+
+
+def to_nhwc_bf16(t):  # fp32 NCHW (cpu) -> bf16 NHWC (gpu), via torch (test plumbing)
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+
+
+def from_nhwc(t):  # bf16/fp32 NHWC (gpu) -> fp32 NCHW (cpu)
+    return t.float().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rel_err(a, ref):
+    return (a - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+
+
+def assert_bf16_close(a, ref, name, extra=0.0):
+    """a is a bf16-rounded version of something that should equal ref up to fp32 accumulation noise."""
+    tol = (2.0 ** -8) * ref.abs() + (1e-5 + extra) * ref.abs().max()
+    bad = (a - ref).abs() > tol
+    assert not bad.any(), f"{name}: {int(bad.sum())} / {bad.numel()} outside bf16 tolerance, max rel-to-max err {rel_err(a, ref):.3e}"
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------ layout
+def test_layout_roundtrip(ops):
+    x = gen(2, 5, 7, 9, seed=1)
+    y = ops.nchw_to_nhwc_bf16(x.to(DEV), c_pad=8)
+    assert y.shape == (2, 7, 9, 8)
+    assert torch.equal(from_nhwc(y)[:, :5], bf(x))
+    assert torch.equal(from_nhwc(y)[:, 5:], torch.zeros(2, 3, 7, 9))
+    back = ops.nhwc_bf16_to_nchw(y, c=5).cpu()
+    assert torch.equal(back, bf(x))
+    s = gen(2, 16, 5, 6, seed=2).to(DEV)
+    assert torch.equal(ops.nhwc_f32_to_nchw(ops.nchw_to_nhwc_f32(s)), s)
+    assert torch.equal(ops.nchw_to_nhwc_f32(s).cpu(), s.cpu().permute(0, 2, 3, 1).contiguous())
+
+
+def _pack_ref(w, transpose):
+    """Python statement of the packed image [K32][9][4][out_pad][8] (include/fosvos_hip.h)."""
+    co, ci = w.shape[:2]
+    wf = w.reshape(co, ci, 9)
+    if transpose:  # (out=ci, in=co, tap' = 8 - tap)
+        wf = wf.flip(2).permute(1, 0, 2)
+    out_ch, in_ch = wf.shape[:2]
+    out_pad, in_pad = (out_ch + 15) // 16 * 16, (in_ch + 31) // 32 * 32
+    p = torch.zeros(out_pad, in_pad, 9)
+    p[:out_ch, :in_ch] = wf
+    p = p.reshape(out_pad, in_pad // 32, 4, 8, 9).permute(1, 4, 2, 0, 3).contiguous()  # [K32][9][4][out][8]
+    return p.reshape(-1)
+
+
+@pytest.mark.parametrize("co,ci", [(64, 64), (16, 128), (128, 64), (64, 3), (16, 40)])
+def test_pack_weights(ops, co, ci):
+    w = gen(co, ci, 3, 3, seed=3)
+    fwd, dgr = ops.pack_conv3x3_weights(w.to(DEV))
+    assert torch.equal(fwd.float().cpu(), bf(_pack_ref(w, False)))
+    assert torch.equal(dgr.float().cpu(), bf(_pack_ref(w, True)))
+
+
+# ------------------------------------------------------------------------------------------ conv1_1
+@pytest.mark.parametrize("n,h,w", [(1, 48, 86), (2, 61, 107), (1, 5, 3), (1, 4, 64), (1, 9, 130)])
+def test_conv_first_fwd(ops, n, h, w):
+    x = gen(n, 3, h, w, seed=4, scale=60.0)
+    wt = gen(64, 3, 3, 3, seed=5, scale=0.2)
+    b = gen(64, seed=6, scale=0.5)
+    ref = F.relu(F.conv2d(x, wt, b, padding=1))
+    y = ops.conv3x3_first_fwd(x.to(DEV), wt.to(DEV), b.to(DEV))
+    assert y.shape == (n, h, w, 64) and y.dtype == torch.bfloat16
+    assert_bf16_close(from_nhwc(y), ref, "conv_first_fwd")
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 48, 86), (2, 33, 47), (1, 3, 300)])
+def test_conv_first_wgrad(ops, n, h, w):
+    x = gen(n, 3, h, w, seed=7, scale=60.0)
+    dy = bf(gen(n, 64, h, w, seed=8))
+    wt = torch.zeros(64, 3, 3, 3, requires_grad=True)
+    b = torch.zeros(64, requires_grad=True)
+    F.conv2d(x, wt, b, padding=1).backward(dy)
+    dw, db = ops.conv3x3_first_wgrad(x.to(DEV), to_nhwc_bf16(dy))
+    assert rel_err(dw.cpu(), wt.grad) < 2e-5
+    assert rel_err(db.cpu(), b.grad) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ MFMA conv
+CONV_CASES = [
+    # n, h, w, ci, co  -> exercises each tile configuration and ragged edges
+    (1, 64, 96, 64, 64),     # TileBig
+    (1, 61, 107, 64, 128),   # TileBig/Mid, ragged
+    (2, 30, 54, 128, 64),    # TileMid/Small
+    (1, 8, 16, 64, 64),      # single small tile
+    (1, 15, 27, 256, 128),   # TileSmall, 8 K chunks
+    (1, 7, 5, 64, 64),       # smaller than one tile
+    (1, 1, 1, 64, 64),       # degenerate
+    (1, 120, 214, 64, 64),   # TileBig with >512 blocks
+]
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", CONV_CASES)
+def test_conv3x3_fwd(ops, n, h, w, ci, co):
+    x = bf(gen(n, ci, h, w, seed=10))
+    wt = gen(co, ci, 3, 3, seed=11, scale=math.sqrt(2.0 / (9 * ci)))
+    b = gen(co, seed=12, scale=0.2)
+    ref = F.relu(F.conv2d(x, bf(wt), b, padding=1))
+    wf, _ = ops.pack_conv3x3_weights(wt.to(DEV))
+    y = ops.conv3x3_fwd(to_nhwc_bf16(x), wf, b.to(DEV), ci, co, relu=True)
+    assert y.shape == (n, h, w, co)
+    assert_bf16_close(from_nhwc(y), ref, f"conv3x3_fwd {n}x{h}x{w} {ci}->{co}")
+    # no-ReLU, no-bias variant
+    ref2 = F.conv2d(x, bf(wt), None, padding=1)
+    y2 = ops.conv3x3_fwd(to_nhwc_bf16(x), wf, None, ci, co, relu=False)
+    assert_bf16_close(from_nhwc(y2), ref2, "conv3x3_fwd linear")
+
+
+@pytest.mark.parametrize("n,h,w,ci", [(1, 120, 214, 128), (1, 30, 54, 512), (2, 15, 27, 256), (1, 3, 2, 128),
+                                       (1, 300, 300, 128)])
+def test_conv3x3_side_prep_f32(ops, n, h, w, ci):
+    """16-channel fp32-output variant (side_prep, no ReLU)."""
+    x = bf(gen(n, ci, h, w, seed=13))
+    wt = gen(16, ci, 3, 3, seed=14, scale=math.sqrt(1.0 / (9 * ci)))
+    b = gen(16, seed=15, scale=0.2)
+    ref = F.conv2d(x, bf(wt), b, padding=1)
+    wf, _ = ops.pack_conv3x3_weights(wt.to(DEV))
+    y = ops.conv3x3_fwd(to_nhwc_bf16(x), wf, b.to(DEV), ci, 16, relu=False, out_f32=True)
+    assert y.dtype == torch.float32 and y.shape == (n, h, w, 16)
+    assert rel_err(from_nhwc(y), ref) < 2e-5
+
+
+def test_conv3x3_fwd_scaling_full_size(ops):
+    """Size-independent property at a BASELINE-size map (240x427, stage 2): conv(2a) == 2 conv(a) bit
+    for bit (a power-of-two scale commutes with every rounding), and conv(0) == 0."""
+    ci, co, h, w = 64, 64, 240, 427
+    a = bf(gen(1, ci, h, w, seed=16))
+    wt = gen(co, ci, 3, 3, seed=18, scale=0.05)
+    wf, _ = ops.pack_conv3x3_weights(wt.to(DEV))
+    ya = ops.conv3x3_fwd(to_nhwc_bf16(a), wf, None, ci, co, relu=False).float()
+    y2 = ops.conv3x3_fwd(to_nhwc_bf16(2 * a), wf, None, ci, co, relu=False).float()
+    assert torch.equal(y2, 2 * ya)
+    y0 = ops.conv3x3_fwd(to_nhwc_bf16(torch.zeros_like(a)), wf, None, ci, co, relu=False).float()
+    assert not y0.any()
+    # spot-check 2000 random outputs against the oracle arithmetic
+    g = torch.Generator().manual_seed(19)
+    ys = torch.randint(0, h, (2000,), generator=g)
+    xs = torch.randint(0, w, (2000,), generator=g)
+    cs = torch.randint(0, co, (2000,), generator=g)
+    ap = F.pad(a, [1, 1, 1, 1])
+    wb = bf(wt)
+    ref = torch.stack([(ap[0, :, y:y + 3, x:x + 3] * wb[c]).sum() for y, x, c in zip(ys.tolist(), xs.tolist(), cs.tolist())])
+    got = ya.cpu()[0, ys, xs, cs]
+    assert_bf16_close(got, ref, "full-size spot check")
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", [(1, 64, 96, 64, 64), (1, 61, 107, 64, 128), (2, 30, 54, 128, 64),
+                                          (1, 15, 27, 256, 128), (1, 7, 5, 64, 64)])
+def test_conv3x3_dgrad(ops, n, h, w, ci, co):
+    dy = bf(gen(n, co, h, w, seed=20))
+    wt = gen(co, ci, 3, 3, seed=21, scale=math.sqrt(2.0 / (9 * ci)))
+    xin = torch.zeros(n, ci, h, w, requires_grad=True)
+    F.conv2d(xin, bf(wt), None, padding=1).backward(dy)
+    ref = xin.grad
+    _, wd = ops.pack_conv3x3_weights(wt.to(DEV))
+    dx = ops.conv3x3_dgrad(to_nhwc_bf16(dy), wd, ci, co)
+    assert_bf16_close(from_nhwc(dx), ref, "conv3x3_dgrad")
+    # fused ReLU mask + addend (addend aliasing the output)
+    act = bf(F.relu(gen(n, ci, h, w, seed=22)))
+    add = bf(gen(n, ci, h, w, seed=23))
+    ref2 = bf(bf(ref) * (act > 0).float() + add)
+    add_dev = to_nhwc_bf16(add)
+    dx2 = ops.conv3x3_dgrad(to_nhwc_bf16(dy), wd, ci, co, relu_src=to_nhwc_bf16(act), addend=add_dev, out=add_dev)
+    assert dx2.data_ptr() == add_dev.data_ptr()
+    got = from_nhwc(dx2)
+    tol = (2.0 ** -7) * ref2.abs() + 1e-5 * ref2.abs().max() + (2.0 ** -8) * ref.abs()  # two roundings
+    assert ((got - ref2).abs() <= tol).all(), f"dgrad mask+add: rel err {rel_err(got, ref2):.3e}"
+
+
+def test_conv3x3_dgrad_side(ops):
+    """side_prep dgrad: 16 real channels zero-padded to 32 on the contraction side."""
+    n, h, w, ci, co = 1, 30, 54, 128, 16
+    dy = bf(gen(n, co, h, w, seed=24))
+    wt = gen(co, ci, 3, 3, seed=25, scale=0.05)
+    xin = torch.zeros(n, ci, h, w, requires_grad=True)
+    F.conv2d(xin, bf(wt), None, padding=1).backward(dy)
+    _, wd = ops.pack_conv3x3_weights(wt.to(DEV))
+    dy_pad = torch.zeros(n, h, w, 32, dtype=torch.bfloat16, device=DEV)
+    dy_pad[..., :16] = to_nhwc_bf16(dy)
+    dx = ops.conv3x3_dgrad(dy_pad, wd, ci, co)
+    assert_bf16_close(from_nhwc(dx), xin.grad, "conv3x3_dgrad side")
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", [(1, 64, 96, 64, 64), (1, 61, 107, 64, 128), (2, 30, 54, 128, 64),
+                                          (1, 15, 27, 256, 128), (1, 7, 5, 64, 64), (1, 17, 33, 128, 16),
+                                          (1, 120, 214, 64, 64)])
+def test_conv3x3_wgrad(ops, n, h, w, ci, co):
+    x = bf(gen(n, ci, h, w, seed=30))
+    dy = bf(gen(n, co, h, w, seed=31))
+    wt = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    b = torch.zeros(co, requires_grad=True)
+    F.conv2d(x, wt, b, padding=1).backward(dy)
+    cy = (co + 31) // 32 * 32
+    dy_dev = torch.zeros(n, h, w, cy, dtype=torch.bfloat16, device=DEV)
+    dy_dev[..., :co] = to_nhwc_bf16(dy)
+    dw, db = ops.conv3x3_wgrad(to_nhwc_bf16(x), dy_dev, ci, co)
+    assert dw.shape == (co, ci, 3, 3)
+    assert rel_err(dw.cpu(), wt.grad) < 5e-5, f"wgrad rel err {rel_err(dw.cpu(), wt.grad):.3e}"
+    assert rel_err(db.cpu(), b.grad) < 5e-5
+    # accumulate mode and run-to-run determinism (fixed-order slab reduction)
+    dw2, db2 = ops.conv3x3_wgrad(to_nhwc_bf16(x), dy_dev, ci, co, dw=dw.clone(), db=db.clone(), accumulate=True)
+    assert torch.equal(dw2, 2 * dw) and torch.equal(db2, 2 * db)
+    dw3, _ = ops.conv3x3_wgrad(to_nhwc_bf16(x), dy_dev, ci, co)
+    assert torch.equal(dw3, dw)
+
+
+# ------------------------------------------------------------------------------------------ pool
+@pytest.mark.parametrize("n,h,w,c", [(1, 48, 86, 64), (2, 61, 107, 64), (1, 1, 1, 64), (1, 2, 3, 128), (1, 7, 1, 64)])
+def test_maxpool(ops, n, h, w, c):
+    x = bf(F.relu(gen(n, c, h, w, seed=40)))  # ReLU output: many exact zeros and ties
+    xr = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 2, 2, ceil_mode=True)
+    y = ops.maxpool_fwd(to_nhwc_bf16(x))
+    assert y.shape == (n, (h + 1) // 2, (w + 1) // 2, c)
+    assert torch.equal(from_nhwc(y), ref.detach())  # selection: exact
+    dy = bf(gen(*ref.shape, seed=41))
+    ref.backward(dy)
+    dx = ops.maxpool_bwd(to_nhwc_bf16(x), to_nhwc_bf16(dy), relu_mask=False)
+    assert torch.equal(from_nhwc(dx), xr.grad)      # routing to the first maximum: exact
+    dxm = ops.maxpool_bwd(to_nhwc_bf16(x), to_nhwc_bf16(dy), relu_mask=True)
+    assert torch.equal(from_nhwc(dxm), xr.grad * (x > 0).float())
+
+
+# ------------------------------------------------------------------------------------------ head
+def _head_inputs(n, H, W, seed):
+    sizes = []
+    h, w = H, W
+    for _ in range(4):
+        h, w = (h + 1) // 2, (w + 1) // 2
+        sizes.append((h, w))
+    g = torch.Generator().manual_seed(seed)
+    side = [torch.randn(n, 16, hh, ww, generator=g) for hh, ww in sizes]
+    # general per-channel k x k filters (not only bilinear) to exercise the real contract
+    up = []
+    up1 = []
+    for i in range(4):
+        k = 4 << i
+        wt = torch.zeros(16, 16, k, k)
+        base = torch.from_numpy(O.bilinear_kernel(k)).float()
+        for c in range(16):
+            wt[c, c] = base * (1.0 + 0.05 * c) + 0.01 * torch.randn(k, k, generator=g)
+        up.append(wt)
+        up1.append((base * 0.9 + 0.01 * torch.randn(k, k, generator=g)).reshape(1, 1, k, k))
+    dsn_w = torch.randn(4, 16, generator=g) * 0.3
+    dsn_b = torch.randn(4, generator=g) * 0.1
+    fuse_w = torch.randn(64, generator=g) * 0.2
+    fuse_b = torch.randn(1, generator=g)
+    return side, up, up1, dsn_w, dsn_b, fuse_w, fuse_b
+
+
+def _head_ref(side, up, up1, dsn_w, dsn_b, fuse_w, fuse_b, H, W):
+    sides, outs = [], []
+    for i in range(4):
+        f = 2 << i
+        sides.append(O.center_crop(F.conv_transpose2d(side[i], up[i], stride=f), H, W))
+        score = F.conv2d(side[i], dsn_w[i].view(1, 16, 1, 1), dsn_b[i:i + 1])
+        outs.append(O.center_crop(F.conv_transpose2d(score, up1[i], stride=f), H, W))
+    fused = F.conv2d(torch.cat(sides, 1), fuse_w.view(1, 64, 1, 1), fuse_b)
+    return outs + [fused]
+
+
+@pytest.mark.parametrize("n,H,W", [(1, 48, 86), (2, 61, 107), (1, 33, 47), (1, 17, 16)])
+def test_head_fwd_bwd(ops, n, H, W):
+    side, up, up1, dsn_w, dsn_b, fuse_w, fuse_b = _head_inputs(n, H, W, seed=50)
+    leaves = [s.clone().requires_grad_(True) for s in side]
+    dw_l, db_l = dsn_w.clone().requires_grad_(True), dsn_b.clone().requires_grad_(True)
+    fw_l, fb_l = fuse_w.clone().requires_grad_(True), fuse_b.clone().requires_grad_(True)
+    ref = _head_ref(leaves, up, up1, dw_l, db_l, fw_l, fb_l, H, W)
+    dev = lambda t: t.contiguous().to(DEV)
+    side_d = [dev(s.permute(0, 2, 3, 1)) for s in side]
+    idx = torch.arange(16)
+    filt = [dev(u[idx, idx]) for u in up]
+    filt1 = [dev(u[0, 0]) for u in up1]
+    fused, so = ops.head_fwd(side_d, filt, filt1, dev(dsn_w), dev(dsn_b), dev(fuse_w), dev(fuse_b), H, W, True)
+    assert rel_err(fused.cpu(), ref[4].detach()) < 1e-5
+    for i in range(4):
+        assert rel_err(so[i].cpu(), ref[i].detach()) < 1e-5, f"side_out {i}"
+    fused_only, none = ops.head_fwd(side_d, filt, None, None, None, dev(fuse_w), dev(fuse_b), H, W, False)
+    assert none is None and torch.equal(fused_only, fused)
+    # backward: all five upstream gradients
+    g = [gen(n, 1, H, W, seed=60 + i) for i in range(5)]
+    torch.autograd.backward(ref, g)
+    d_side, d_fw, d_fb, d_dw, d_db = ops.head_bwd(side_d, filt, filt1, dev(dsn_w), dev(fuse_w), dev(g[4]),
+                                                  [dev(t) for t in g[:4]], H, W)
+    for i in range(4):
+        got = d_side[i].float().cpu()
+        assert torch.equal(got[..., 16:], torch.zeros_like(got[..., 16:])), "padding channels must be zero"
+        assert_bf16_close(got[..., :16].permute(0, 3, 1, 2), leaves[i].grad, f"d_side {i}")
+    assert rel_err(d_fw.cpu(), fw_l.grad) < 2e-5
+    assert rel_err(d_fb.cpu(), fb_l.grad) < 2e-5
+    assert rel_err(d_dw.cpu(), dw_l.grad) < 2e-5
+    assert rel_err(d_db.cpu(), db_l.grad) < 2e-5
+    # backward: fused gradient only (the online objective)
+    for t in leaves + [fw_l, fb_l]:
+        t.grad = None
+    ref2 = _head_ref(leaves, up, up1, dw_l, db_l, fw_l, fb_l, H, W)
+    ref2[4].backward(g[4])
+    d_side2, d_fw2, d_fb2, a, b = ops.head_bwd(side_d, filt, None, None, dev(fuse_w), dev(g[4]), None, H, W)
+    assert a is None and b is None
+    for i in range(4):
+        assert_bf16_close(d_side2[i].float().cpu()[..., :16].permute(0, 3, 1, 2), leaves[i].grad, f"d_side(fused only) {i}")
+    assert rel_err(d_fw2.cpu(), fw_l.grad) < 2e-5 and rel_err(d_fb2.cpu(), fb_l.grad) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ loss
+@pytest.mark.parametrize("tag", ["kat12", "allneg", "allpos", "extreme", "rand", "soft"])
+def test_cbce_golden(ops, golden, tag):
+    k = golden("kat.npz")
+    x, y = torch.from_numpy(k[f"loss_{tag}_x"]), torch.from_numpy(k[f"loss_{tag}_y"])
+    loss, grad = ops.cbce_loss(x.to(DEV), y.to(DEV), size_average=False)
+    np.testing.assert_allclose(loss.item(), k[f"loss_{tag}_sum"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(grad.cpu().numpy(), k[f"loss_{tag}_grad"], rtol=1e-5, atol=1e-7)
+    loss_a, grad_a = ops.cbce_loss(x.to(DEV), y.to(DEV), size_average=True, grad_scale=0.2)
+    np.testing.assert_allclose(loss_a.item(), k[f"loss_{tag}_avg"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(grad_a.cpu().numpy(), 0.2 * k[f"loss_{tag}_grad"] / x.numel(), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 480, 854), (16, 1, 61, 107), (1, 1, 1, 1), (1, 1, 3, 5)])
+def test_cbce_sizes(ops, shape):
+    x = gen(*shape, seed=70, scale=5.0)
+    _, y = O.synthetic_frame(shape[0], shape[2], shape[3], seed=71)
+    ref = O.cbce_loss(x.double(), y.double(), size_average=False)
+    gref = O.cbce_loss_grad(x.double(), y.double(), size_average=False)
+    loss, grad = ops.cbce_loss(x.to(DEV), y.to(DEV), size_average=False)
+    assert abs(loss.item() - ref.item()) <= 2e-6 * abs(ref.item()) + 1e-6
+    assert rel_err(grad.cpu().double(), gref) < 1e-6
+    loss2, _ = ops.cbce_loss(x.to(DEV), y.to(DEV), size_average=False, want_grad=False)
+    assert loss2.item() == loss.item()  # deterministic reduction
+
+
+# ------------------------------------------------------------------------------------------ SGD
+def test_fused_sgd_matches_torch():
+    from fosvos_hip.sgd import FusedSGD
+    shapes = [(64, 3, 3, 3), (64,), (128, 64, 3, 3), (1, 64, 1, 1), (1,), (7, 5)]
+    g = torch.Generator().manual_seed(80)
+    p_ref = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    p_hip = [p.detach().clone().to(DEV).requires_grad_(True) for p in p_ref]
+
+    def groups(ps):
+        return [{"params": ps[:2], "weight_decay": 2e-4}, {"params": ps[2:4], "lr": 2e-3},
+                {"params": ps[4:5], "lr": 0.0}, {"params": ps[5:], "lr": 1e-4, "weight_decay": 1e-2}]
+
+    o_ref = torch.optim.SGD(groups(p_ref), lr=1e-3, momentum=0.9)
+    o_hip = FusedSGD(groups(p_hip), lr=1e-3, momentum=0.9)
+    for step in range(4):
+        for pr, ph in zip(p_ref, p_hip):
+            gr = torch.randn(pr.shape, generator=g)
+            pr.grad = gr.clone()
+            ph.grad = gr.clone().to(DEV)
+        if step == 2:  # a parameter without gradient is skipped
+            p_ref[5].grad = None
+            p_hip[5].grad = None
+        o_ref.step()
+        o_hip.step()
+        for pr, ph in zip(p_ref, p_hip):
+            np.testing.assert_allclose(ph.detach().cpu().numpy(), pr.detach().numpy(), rtol=2e-6, atol=1e-7)
