@@ -37,6 +37,7 @@ class FusedSGD(optim.SGD):
         device = None
         max_numel = 0
         keep_alive = []
+        updated = []
         for group in self.param_groups:
             if group.get("dampening", 0) != 0 or group.get("nesterov", False):
                 raise NotImplementedError("FusedSGD: dampening/nesterov are not implemented")
@@ -65,6 +66,7 @@ class FusedSGD(optim.SGD):
                 device = p.device
                 entries.append((p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), float(group["lr"]),
                                 float(group["weight_decay"])))
+                updated.append(p)
                 max_numel = max(max_numel, p.numel())
         if not entries:
             return loss
@@ -87,5 +89,9 @@ class FusedSGD(optim.SGD):
         idx = device.index if device.index is not None else torch.cuda.current_device()
         check(lib().fosvos_sgd_momentum_step(self._dev_table.data_ptr(), n, max_numel, momentum, 0, idx,
                                              torch.cuda.current_stream(idx).cuda_stream), "sgd_momentum_step")
+        # the kernel wrote through raw pointers: tell torch the tensors changed, so that version-keyed caches
+        # (the packed bf16 weight images) and autograd's saved-tensor checks see the update
+        for p in updated:
+            torch.autograd.graph.increment_version(p)
         del keep_alive
         return loss

@@ -226,7 +226,7 @@ def main() -> None:
         loops[f"groups_{mode}"] = np.array(rows)
 
     # online: 10 iterations, step every 5 (src/train_online.py:70-101), two alternating frame sizes
-    for tag, lr in (("lr1e-8", 1e-8), ("lr1e-6", 1e-6)):
+    for tag, lr in (("lr1e-8", 1e-8), ("lr1e-9", 1e-9)):
         net, sd0 = ref_net(6)
         cls = RNP.VGGOnlineProvider
         opt = cls.get_optimizer(provider(cls, net), learning_rate=lr)

@@ -146,10 +146,56 @@ def center_crop(x: torch.Tensor, height: int, width: int) -> torch.Tensor:
     return F.pad(x, [-l, -r, -t, -b])
 
 
+class _RoundBoth(torch.autograd.Function):
+    """bf16 rounding of the value in forward and of the gradient in backward (an activation the HIP
+    path stores in bf16 together with its gradient)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundValue(torch.autograd.Function):
+    """bf16 rounding of the value only (the packed MFMA weight image; its gradient stays fp32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGrad(torch.autograd.Function):
+    """identity in forward, bf16 rounding of the gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
 def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor,
-            return_intermediates: bool = False):
-    """OSVOS_VGG.forward (src/networks/osvos_vgg.py:61-83): list of 5 logit maps [N,1,H,W]."""
+            return_intermediates: bool = False, emulate_bf16: bool = False):
+    """OSVOS_VGG.forward (src/networks/osvos_vgg.py:61-83): list of 5 logit maps [N,1,H,W].
+
+    emulate_bf16=True re-states the SAME graph with the HIP path's storage precision: conv outputs and
+    the gradients flowing through them rounded to bf16, MFMA weight images rounded to bf16, everything
+    accumulated in fp32; conv1_1 (fp32 VALU), side_prep outputs and the head stay fp32.  It is the fp32
+    reference plus rounding at exactly the points where the kernels round, which separates "precision
+    scheme" from "kernel correctness" in the parity tests."""
     H, W = int(x.shape[-2]), int(x.shape[-1])
+    rb = _RoundBoth.apply if emulate_bf16 else (lambda t: t)
+    rv = _RoundValue.apply if emulate_bf16 else (lambda t: t)
+    rg = _RoundGrad.apply if emulate_bf16 else (lambda t: t)
     feats: List[torch.Tensor] = []
     sides: List[torch.Tensor] = []
     side_out: List[torch.Tensor] = []
@@ -157,16 +203,19 @@ def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor,
     h = x
     for s, chans in enumerate(STAGE_CHANNELS):
         if s > 0:
-            h = F.max_pool2d(h, kernel_size=2, stride=2, ceil_mode=True)
+            h = rg(F.max_pool2d(h, kernel_size=2, stride=2, ceil_mode=True))
         for j in range(len(chans)):
             m = conv_module_index(s, j)
-            h = F.relu(F.conv2d(h, sd[f"stages.{s}.{m}.weight"], sd[f"stages.{s}.{m}.bias"], padding=1))
+            w = sd[f"stages.{s}.{m}.weight"]
+            if not (s == 0 and j == 0):
+                w = rv(w)  # conv1_1 runs on fp32 weights and the fp32 frame
+            h = rb(F.relu(F.conv2d(h, w, sd[f"stages.{s}.{m}.bias"], padding=1)))
         feats.append(h)
         if s == 0:
             continue
         i = s - 1
         stride = 2 ** s
-        prep = F.conv2d(h, sd[f"side_prep.{i}.weight"], sd[f"side_prep.{i}.bias"], padding=1)
+        prep = rg(F.conv2d(rg(h), rv(sd[f"side_prep.{i}.weight"]), sd[f"side_prep.{i}.bias"], padding=1))
         side_prep_out.append(prep)
         up = F.conv_transpose2d(prep, sd[f"upscale.{i}.weight"], stride=stride)
         sides.append(center_crop(up, H, W))

@@ -206,7 +206,8 @@ def test_conv3x3_dgrad(ops, n, h, w, ci, co):
     dx2 = ops.conv3x3_dgrad(to_nhwc_bf16(dy), wd, ci, co, relu_src=to_nhwc_bf16(act), addend=add_dev, out=add_dev)
     assert dx2.data_ptr() == add_dev.data_ptr()
     got = from_nhwc(dx2)
-    tol = (2.0 ** -7) * ref2.abs() + 1e-5 * ref2.abs().max() + (2.0 ** -8) * ref.abs()  # two roundings
+    # two roundings: the intermediate may land on the neighbouring bf16 (1 ulp <= 2^-7 relative)
+    tol = (2.0 ** -7) * ref2.abs() + 1e-5 * ref2.abs().max() + (2.0 ** -7) * ref.abs()
     assert ((got - ref2).abs() <= tol).all(), f"dgrad mask+add: rel err {rel_err(got, ref2):.3e}"
 
 
@@ -319,7 +320,7 @@ def test_head_fwd_bwd(ops, n, H, W):
     for i in range(4):
         assert rel_err(so[i].cpu(), ref[i].detach()) < 1e-5, f"side_out {i}"
     fused_only, none = ops.head_fwd(side_d, filt, None, None, None, dev(fuse_w), dev(fuse_b), H, W, False)
-    assert none is None and torch.equal(fused_only, fused)
+    assert none is None and rel_err(fused_only, fused) < 1e-6  # other template instance: FMA order may differ
     # backward: all five upstream gradients
     g = [gen(n, 1, H, W, seed=60 + i) for i in range(5)]
     torch.autograd.backward(ref, g)

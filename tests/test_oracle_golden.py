@@ -16,10 +16,11 @@ def T(a):
 def check_digest(t, m, idx, smp, rtol=RTOL, scale=None):
     f = t.detach().reshape(-1).double()
     got = np.array([f.sum().item(), f.abs().sum().item(), (f * f).sum().item()])
+    slack = 0.0 if scale is None else scale * f.numel()  # per-element absolute slack, summed
     ref_scale = max(abs(m[1]), 1e-30)
-    assert abs(got[0] - m[0]) <= rtol * ref_scale * 10
-    assert abs(got[1] - m[1]) <= rtol * ref_scale * 10
-    assert abs(got[2] - m[2]) <= rtol * max(m[2], 1e-30) * 10
+    assert abs(got[0] - m[0]) <= rtol * ref_scale * 10 + slack
+    assert abs(got[1] - m[1]) <= rtol * ref_scale * 10 + slack
+    assert abs(got[2] - m[2]) <= rtol * max(m[2], 1e-30) * 10 + slack * np.sqrt(max(m[2], 1e-30))
     s = t.detach().reshape(-1)[T(idx)].double().numpy()
     tol = rtol * (np.abs(smp).max() + 1e-30) * 10 if scale is None else scale
     np.testing.assert_allclose(s, smp, rtol=rtol * 10, atol=tol)
@@ -163,7 +164,7 @@ def test_optimizer_groups(golden):
         assert rows == [str(s) for s in k[f"groups_{mode}"]]
 
 
-@pytest.mark.parametrize("tag,lr", [("lr1e-8", 1e-8), ("lr1e-6", 1e-6)])
+@pytest.mark.parametrize("tag,lr", [("lr1e-8", 1e-8), ("lr1e-9", 1e-9)])
 def test_online_loop(golden, tag, lr):
     k = golden("loops.npz")
     sd = O.make_state_dict(6)
@@ -174,8 +175,10 @@ def test_online_loop(golden, tag, lr):
     for nm in sd:
         d = final[nm].double() - sd[nm].double()
         m = k[f"online_{tag}_delta_{nm}_m"]
+        # the applied update sits near the fp32 resolution of the weight: allow 2 ulps of it on top
+        ulp = float(np.spacing(np.float32(sd[nm].abs().max().item())))
         check_digest(d, m, k[f"online_{tag}_delta_{nm}_i"], k[f"online_{tag}_delta_{nm}_s"], rtol=2e-3,
-                     scale=2e-3 * (np.abs(k[f"online_{tag}_delta_{nm}_s"]).max() + 1e-30) + 1e-12)
+                     scale=2e-3 * (np.abs(k[f"online_{tag}_delta_{nm}_s"]).max() + 1e-30) + 2 * ulp)
     np.testing.assert_allclose(final["fuse.weight"].numpy(), k[f"online_{tag}_fuse_weight"], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(final["stages.0.0.bias"].numpy(), k[f"online_{tag}_stage00_bias"], rtol=1e-6, atol=1e-9)
     # frozen / unoptimised tensors do not move (src/util/network_provider.py:154-155, score_dsn absent)
@@ -192,8 +195,9 @@ def test_offline_loop(golden):
     np.testing.assert_allclose(np.array(trace), k["offline_loss"], rtol=2e-5)
     for nm in sd:
         d = final[nm].double() - sd[nm].double()
+        ulp = float(np.spacing(np.float32(sd[nm].abs().max().item())))
         check_digest(d, k[f"offline_delta_{nm}_m"], k[f"offline_delta_{nm}_i"], k[f"offline_delta_{nm}_s"],
-                     rtol=2e-3, scale=2e-3 * (np.abs(k[f"offline_delta_{nm}_s"]).max() + 1e-30) + 1e-12)
+                     rtol=2e-3, scale=2e-3 * (np.abs(k[f"offline_delta_{nm}_s"]).max() + 1e-30) + 2 * ulp)
 
 
 def test_e2e_frame(golden):
@@ -215,3 +219,18 @@ def test_e2e_frame(golden):
     np.testing.assert_allclose(O.cbce_loss(outs[-1], gt, False).item(), float(k["loss_fused_sum"]), rtol=1e-5)
     for i in range(4):
         check_digest(outs[i], k[f"side{i}_m"], k[f"side{i}_i"], k[f"side{i}_s"], rtol=1e-4)
+
+
+def test_bf16_emulation_mode_is_close_to_fp32():
+    """The bf16-emulating oracle mode (used to separate precision scheme from kernel correctness in the GPU
+    tests) is the same graph plus rounding: its logits stay within 2 % of the fp32 logit range."""
+    sd = O.make_state_dict(3)
+    x, gt = O.synthetic_frame(1, 48, 86, seed=103)
+    ref = O.forward(sd, x)
+    emu = O.forward(sd, x, emulate_bf16=True)
+    for a, b in zip(emu, ref):
+        assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item()
+    params = O.leaf_params(sd)
+    O.cbce_loss(O.forward(params, x, emulate_bf16=True)[-1], gt, False).backward()
+    g = params["stages.2.3.weight"].grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
