@@ -105,11 +105,11 @@ __global__ __launch_bounds__(256) void k_first_fwd(const float *__restrict__ fra
 // wave-uniform (the compiler keeps them on the scalar path: v_fmac with an SGPR operand).
 // Each block writes one slab of Co*28 floats; k_first_reduce sums the slabs in index order.
 constexpr int WG_PIX = 256;
+constexpr int WG_ROWS = 8;  // image rows swept by one block
 
 __global__ __launch_bounds__(256) void k_first_wgrad(const float *__restrict__ frame, const uint16_t *__restrict__ dy,
                                                       float *__restrict__ slabs, int H, int W) {
     const int n = blockIdx.z;
-    const int gy = blockIdx.y;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int co = threadIdx.x & 63;
     const int xs = blockIdx.x * WG_PIX + q * 64;
@@ -120,6 +120,8 @@ __global__ __launch_bounds__(256) void k_first_wgrad(const float *__restrict__ f
     for (int k = 0; k < 27; ++k) acc[k] = 0.f;
     float accb = 0.f;
     const int xe = min(xs + 64, W);
+    const int gy_end = min((int)(blockIdx.y + 1) * WG_ROWS, H);
+    for (int gy = blockIdx.y * WG_ROWS; gy < gy_end; ++gy)
     for (int x = xs; x < xe; ++x) {
         const float g = bf2f(dy[(((int64_t)n * H + gy) * W + x) * CO + co]);
         accb += g;
@@ -151,23 +153,20 @@ __global__ __launch_bounds__(256) void k_first_wgrad(const float *__restrict__ f
     }
 }
 
-// out[co*27 + k] = sum over slabs of slab[k][co]; bias = row 27.  One thread per output, slabs
-// walked in index order with 4 independent partial chains (fixed association).
+// out[co*27 + k] = sum over slabs of slab[k][co]; bias = row 27.  Block = 64 outputs x 4 slab groups; group
+// g sums slabs g, g+4, ... in order, then the 4 group sums are added in order (deterministic).
 __global__ __launch_bounds__(256) void k_first_reduce(const float *__restrict__ slabs, int n_slabs,
                                                        float *__restrict__ dw, float *__restrict__ db) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 28 * CO) return;
+    __shared__ float red[4][64];
+    const int il = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;  // 28*CO outputs, CO == 64: one block per k
+    float a = 0.f;
+    for (int s = g; s < n_slabs; s += 4) a += slabs[(int64_t)s * 28 * CO + i];
+    red[g][il] = a;
+    __syncthreads();
+    if (g != 0) return;
+    const float v = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
     const int k = i / CO, c = i % CO;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int s = 0;
-    for (; s + 3 < n_slabs; s += 4) {
-        a0 += slabs[(int64_t)(s + 0) * 28 * CO + i];
-        a1 += slabs[(int64_t)(s + 1) * 28 * CO + i];
-        a2 += slabs[(int64_t)(s + 2) * 28 * CO + i];
-        a3 += slabs[(int64_t)(s + 3) * 28 * CO + i];
-    }
-    for (; s < n_slabs; ++s) a0 += slabs[(int64_t)s * 28 * CO + i];
-    const float v = (a0 + a1) + (a2 + a3);
     if (k < 27)
         dw[c * 27 + k] = v;
     else if (db)
@@ -189,7 +188,7 @@ extern "C" int fosvos_conv3x3_first_fwd(const float *frame, const float *w, cons
 }
 
 extern "C" size_t fosvos_conv3x3_first_wgrad_workspace_bytes(int N, int H, int W, int Co) {
-    return (size_t)N * H * cdiv(W, WG_PIX) * 28 * (size_t)Co * sizeof(float);
+    return (size_t)N * cdiv(H, WG_ROWS) * cdiv(W, WG_PIX) * 28 * (size_t)Co * sizeof(float);
 }
 
 extern "C" int fosvos_conv3x3_first_wgrad(const float *frame, const uint16_t *dy, float *dw, float *db, int N, int H,
@@ -203,12 +202,12 @@ extern "C" int fosvos_conv3x3_first_wgrad(const float *frame, const uint16_t *dy
     FOSVOS_REQUIRE(workspace_bytes >= need, FOSVOS_E_WORKSPACE, "conv3x3_first_wgrad: workspace %zu < %zu",
                    workspace_bytes, need);
     FOSVOS_ENTER(device);
-    dim3 grid((unsigned)cdiv(W, WG_PIX), (unsigned)H, (unsigned)N);
+    dim3 grid((unsigned)cdiv(W, WG_PIX), (unsigned)cdiv(H, WG_ROWS), (unsigned)N);
     float *slabs = reinterpret_cast<float *>(workspace);
     hipLaunchKernelGGL(k_first_wgrad, grid, dim3(256), 0, (hipStream_t)stream, frame, dy, slabs, H, W);
     FOSVOS_LAUNCH_CHECK();
     const int n_slabs = (int)(grid.x * grid.y * grid.z);
-    hipLaunchKernelGGL(k_first_reduce, dim3((unsigned)cdiv(28 * CO, 256)), dim3(256), 0, (hipStream_t)stream, slabs,
+    hipLaunchKernelGGL(k_first_reduce, dim3(28), dim3(256), 0, (hipStream_t)stream, slabs,
                        n_slabs, dw, db);
     FOSVOS_LAUNCH_CHECK();
     return FOSVOS_OK;

@@ -13,8 +13,8 @@
 //
 // Workgroup = 4 waves: co block (64 or 16) shared by all waves, wave w owns ci 16w..16w+15 of a
 // 64-wide ci block, all 9 taps: 4 x 9 accumulators (144 VGPRs).  The pixel range is split over
-// blockIdx.x; each split writes one fp32 slab [tap][co][ci] and k_wgrad_reduce sums the slabs in
-// index order, so results are bitwise reproducible (no float atomics).
+// blockIdx.x; each split writes one fp32 slab [tap][co][ci]; k_wgrad_fold / k_wgrad_final sum the slabs in
+// a fixed order, so results are bitwise reproducible (no float atomics).
 #include "common.hpp"
 
 using namespace fosvos;
@@ -137,29 +137,41 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs a) {
             }
 }
 
-// dw[(co*Ci + ci)*9 + tap] (+)= sum_s slab[s][tap][co][ci]; one thread per (co, ci)
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ slabs, int S, int Co, int Cor, int Ci,
-                                                       int accumulate, float *__restrict__ dw) {
-    const int64_t i = blockIdx.x * 256LL + threadIdx.x;
-    if (i >= (int64_t)Co * Ci) return;
-    const int ci = (int)(i % Ci), co = (int)(i / Ci);
-    float out[9];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const float *p = slabs + ((int64_t)tap * Cor + co) * Ci + ci;
-        const int64_t stride = 9LL * Cor * Ci;
-        float a0 = 0.f, a1 = 0.f;
-        int s = 0;
-        for (; s + 1 < S; s += 2) {
-            a0 += p[s * stride];
-            a1 += p[(s + 1) * stride];
-        }
-        if (s < S) a0 += p[s * stride];
-        out[tap] = a0 + a1;
+// ---- slab reduction, two fully coalesced stages
+// stage 1 (only when S > kFoldTo): fold the S slabs into kFoldTo partial slabs, slab s -> partial s % kFoldTo,
+// each summed in increasing s (fixed order).  float4 per thread, grid = (E/1024, kFoldTo).
+constexpr int kFoldTo = 8;
+
+__global__ __launch_bounds__(256) void k_wgrad_fold(const float *__restrict__ slabs, int S, int64_t E,
+                                                     float *__restrict__ folded) {
+    const int64_t i4 = blockIdx.x * 256LL + threadIdx.x;  // float4 index
+    if (i4 * 4 >= E) return;
+    const int y = blockIdx.y;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = y; s < S; s += kFoldTo) {
+        const float4 v = *reinterpret_cast<const float4 *>(slabs + (int64_t)s * E + i4 * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    float *d = dw + i * 9;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) d[tap] = accumulate ? d[tap] + out[tap] : out[tap];
+    *reinterpret_cast<float4 *>(folded + (int64_t)y * E + i4 * 4) = acc;
+}
+
+// stage 2: block = (co, 64 consecutive ci): sum the <= kFoldTo slabs [tap][co][ci] (64-float coalesced runs),
+// transpose through LDS and write the 576 contiguous floats dw[(co*Ci + ci0)*9 ...] (OIHW).
+__global__ __launch_bounds__(256) void k_wgrad_final(const float *__restrict__ slabs, int S, int Co, int Cor, int Ci,
+                                                      int accumulate, float *__restrict__ dw) {
+    __shared__ float tile[64 * 9];
+    const int ci0 = blockIdx.x * 64, co = blockIdx.y;
+    const int64_t E = 9LL * Cor * Ci;
+    for (int e = threadIdx.x; e < 576; e += 256) {
+        const int tap = e >> 6, cil = e & 63;
+        const float *p = slabs + ((int64_t)tap * Cor + co) * Ci + ci0 + cil;
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += p[(int64_t)s * E];
+        tile[cil * 9 + tap] = a;
+    }
+    __syncthreads();
+    float *d = dw + ((int64_t)co * Ci + ci0) * 9;
+    for (int e = threadIdx.x; e < 576; e += 256) d[e] = accumulate ? d[e] + tile[e] : tile[e];
 }
 
 // ---- bias gradient: column sums of the [pixels][Cy] bf16 matrix.  Thread = 8 channels; a block
@@ -192,16 +204,24 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const uint16_t *__restri
     }
 }
 
+// block = 64 channels x 4 row groups: group g sums partial blocks g, g+4, ... (fixed order), then LDS
 __global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ partial, int n_blocks, int Cy, int Co,
                                                        int accumulate, float *__restrict__ db) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= Co) return;
+    __shared__ double s[4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double acc = 0.0;
-    for (int b = 0; b < n_blocks; ++b) acc += (double)partial[(int64_t)b * Cy + c];
-    db[c] = accumulate ? db[c] + (float)acc : (float)acc;
+    if (c < Cy)
+        for (int b = g; b < n_blocks; b += 4) acc += (double)partial[(int64_t)b * Cy + c];
+    s[g][cl] = acc;
+    __syncthreads();
+    if (g == 0 && c < Co) {
+        const float v = (float)((s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl]));
+        db[c] = accumulate ? db[c] + v : v;
+    }
 }
 
-constexpr int kColsumBlocks = 512;
+constexpr int kColsumBlocks = 256;
 
 struct Plan {
     int Cor, Cy, bco, tiles_x, tiles_y, n_tiles, tps, S;
@@ -217,12 +237,13 @@ Plan make_plan(int N, int H, int W, int Ci, int Co) {
     p.tiles_y = (int)cdiv(H, TH);
     p.n_tiles = p.tiles_x * p.tiles_y * N;
     const int out_blocks = (p.Cor / p.bco) * (Ci / BCI);
-    int S = (int)cdiv(768, out_blocks);
+    int S = (int)cdiv(512, out_blocks);
     if (S > p.n_tiles) S = p.n_tiles;
     if (S < 1) S = 1;
     p.tps = (int)cdiv(p.n_tiles, S);
     p.S = (int)cdiv(p.n_tiles, p.tps);
-    p.slab_bytes = (size_t)p.S * 9 * p.Cor * Ci * sizeof(float);
+    // S slabs + kFoldTo folded slabs when a fold stage is needed
+    p.slab_bytes = (size_t)(p.S + (p.S > kFoldTo ? kFoldTo : 0)) * 9 * p.Cor * Ci * sizeof(float);
     p.bias_bytes = (size_t)kColsumBlocks * p.Cy * sizeof(float);
     return p;
 }
@@ -259,15 +280,28 @@ extern "C" int fosvos_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, float
         hipLaunchKernelGGL(k_wgrad<16>, grid, dim3(256), lds, st, a);
     }
     FOSVOS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)cdiv((int64_t)Co * Ci, 256)), dim3(256), 0, st, a.slabs, p.S, Co,
-                       p.Cor, Ci, accumulate, dw);
-    FOSVOS_LAUNCH_CHECK();
+    {
+        const int64_t E = 9LL * p.Cor * Ci;
+        const float *src = a.slabs;
+        int n_src = p.S;
+        if (p.S > kFoldTo) {
+            float *folded = a.slabs + (int64_t)p.S * E;
+            hipLaunchKernelGGL(k_wgrad_fold, dim3((unsigned)cdiv(E / 4, 256), kFoldTo), dim3(256), 0, st, a.slabs, p.S, E,
+                               folded);
+            FOSVOS_LAUNCH_CHECK();
+            src = folded;
+            n_src = kFoldTo;
+        }
+        hipLaunchKernelGGL(k_wgrad_final, dim3((unsigned)(Ci / 64), (unsigned)Co), dim3(256), 0, st, src, n_src, Co, p.Cor,
+                           Ci, accumulate, dw);
+        FOSVOS_LAUNCH_CHECK();
+    }
     if (db) {
         float *partial = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + p.slab_bytes);
         const int64_t rows = (int64_t)N * H * W;
         hipLaunchKernelGGL(k_colsum_partial, dim3(kColsumBlocks), dim3(256), 0, st, dy, rows, p.Cy, partial);
         FOSVOS_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)cdiv(Co, 256)), dim3(256), 0, st, partial, kColsumBlocks, p.Cy,
+        hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)cdiv(p.Cy, 64)), dim3(256), 0, st, partial, kColsumBlocks, p.Cy,
                            Co, accumulate, db);
         FOSVOS_LAUNCH_CHECK();
     }

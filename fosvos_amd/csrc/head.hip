@@ -183,26 +183,38 @@ struct FinishArgs {
     int n_bias;
 };
 
-// One block per scale (+ one for the bias): thread t < 48 sums column t of the scale's slabs in
-// index order (fp64), deterministic.
-__global__ __launch_bounds__(64) void k_head_finish(FinishArgs fa, float *__restrict__ d_fuse_w,
-                                                     float *__restrict__ d_fuse_b, float *__restrict__ d_dsn_w,
-                                                     float *__restrict__ d_dsn_b) {
+// One block per scale (+ one for the bias): 16 row groups x 48 columns; group g sums slabs g, g+16, ...
+// (fixed order, fp64), then the 16 group sums are added in order: deterministic.
+__global__ __launch_bounds__(768) void k_head_finish(FinishArgs fa, float *__restrict__ d_fuse_w,
+                                                      float *__restrict__ d_fuse_b, float *__restrict__ d_dsn_w,
+                                                      float *__restrict__ d_dsn_b) {
     const int s = blockIdx.x;
+    __shared__ double red[16][48];
     if (s == 4) {
         double acc = 0.0;
-        for (int i = threadIdx.x; i < fa.n_bias; i += 64) acc += (double)fa.bias_partials[i];
+        for (int i = threadIdx.x; i < fa.n_bias; i += 768) acc += (double)fa.bias_partials[i];
         acc = wave_sum(acc);
-        if (threadIdx.x == 0) d_fuse_b[0] = (float)acc;
+        if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < 12; ++w) t += red[0][w];
+            d_fuse_b[0] = (float)t;
+        }
         return;
     }
-    if (threadIdx.x >= 48) return;
-    const int q = threadIdx.x / 16, c = threadIdx.x % 16;
+    const int col = threadIdx.x % 48, g = threadIdx.x / 48;
     double acc = 0.0;
-    for (int b = 0; b < fa.n_slabs[s]; ++b) acc += (double)fa.slabs[s][(int64_t)b * 48 + threadIdx.x];
-    if (q == 0) d_fuse_w[16 * s + c] = (float)acc;
-    if (q == 1 && d_dsn_w) d_dsn_w[16 * s + c] = (float)acc;
-    if (q == 2 && d_dsn_b && c == 0) d_dsn_b[s] = (float)acc;
+    for (int b = g; b < fa.n_slabs[s]; b += 16) acc += (double)fa.slabs[s][(int64_t)b * 48 + col];
+    red[g][col] = acc;
+    __syncthreads();
+    if (g != 0) return;
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += red[k][col];
+    const int q = col / 16, c = col % 16;
+    if (q == 0) d_fuse_w[16 * s + c] = (float)t;
+    if (q == 1 && d_dsn_w) d_dsn_w[16 * s + c] = (float)t;
+    if (q == 2 && d_dsn_b && c == 0) d_dsn_b[s] = (float)t;
 }
 
 constexpr int kBiasBlocks = 512;
@@ -316,7 +328,7 @@ extern "C" int fosvos_head_bwd(const float *const side[4], const int hs[4], cons
                            wsf + off[4]);
         FOSVOS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_head_finish, dim3(5), dim3(64), 0, st, fa, d_fuse_w, d_fuse_b, with_so ? d_dsn_w : nullptr,
+    hipLaunchKernelGGL(k_head_finish, dim3(5), dim3(768), 0, st, fa, d_fuse_w, d_fuse_b, with_so ? d_dsn_w : nullptr,
                        with_so ? d_dsn_b : nullptr);
     FOSVOS_LAUNCH_CHECK();
     return FOSVOS_OK;

@@ -168,11 +168,29 @@ def forward(P: Dict[str, torch.Tensor], packs: PackedWeights, x: torch.Tensor, w
 
 
 def backward(P: Dict[str, torch.Tensor], packs: PackedWeights, sv: "Saved", d_outs: Sequence[Optional[torch.Tensor]],
-             need: Optional[Dict[str, bool]] = None) -> Dict[str, torch.Tensor]:
+             inplace: bool = False) -> Dict[str, torch.Tensor]:
     """Gradients of sum_i <d_outs[i], out_i> wrt every parameter except the (frozen-by-recipe)
     transposed-conv weights.  d_outs[4] is the fused-logit gradient; d_outs[0..3] the side-output ones
-    (all four or none)."""
+    (all four or none).
+
+    inplace=True (the training loops' gradient-accumulation mode): where a parameter already has a
+    contiguous fp32 ``.grad``, the wgrad kernel ADDS into it directly and the parameter is left out of the
+    returned dict - the accumulation ``p.grad += g`` that autograd would run as a separate pass per tensor
+    becomes part of the kernel's epilogue."""
     grads: Dict[str, torch.Tensor] = {}
+
+    def _ok(t: Optional[torch.Tensor]) -> bool:
+        return t is not None and t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+
+    def wgrad(wn: str, bn: str, x: torch.Tensor, dy: torch.Tensor, ci: int, co: int) -> None:
+        pw, pb = P[wn], P[bn]
+        if inplace and _ok(pw.grad) and _ok(pb.grad):
+            ops.conv3x3_wgrad(x, dy, ci, co, dw=pw.grad, db=pb.grad, accumulate=True)
+            torch.autograd.graph.increment_version(pw.grad)
+            torch.autograd.graph.increment_version(pb.grad)
+        else:
+            grads[wn], grads[bn] = ops.conv3x3_wgrad(x, dy, ci, co)
+
     d_fused = d_outs[4]
     d_so = d_outs[:4]
     have_so = [g is not None for g in d_so]
@@ -203,8 +221,7 @@ def backward(P: Dict[str, torch.Tensor], packs: PackedWeights, sv: "Saved", d_ou
         if s > 0:
             i = s - 1
             wn, bn = f"side_prep.{i}.weight", f"side_prep.{i}.bias"
-            dw, db = ops.conv3x3_wgrad(feat, d_side[i], chans[-1], SIDE_CH)
-            grads[wn], grads[bn] = dw, db
+            wgrad(wn, bn, feat, d_side[i], chans[-1], SIDE_CH)
             _, wd = packs.conv(wn, P[wn])
             # gradient wrt the stage output: ReLU-masked side dgrad + what came back through the next pool
             g = ops.conv3x3_dgrad(d_side[i], wd, chans[-1], SIDE_CH, relu_src=feat, addend=g_pool, out=g_pool)
@@ -218,8 +235,7 @@ def backward(P: Dict[str, torch.Tensor], packs: PackedWeights, sv: "Saved", d_ou
                 dw, db = ops.conv3x3_first_wgrad(sv.frame, g)
                 grads[wn], grads[bn] = dw, db
                 break
-            dw, db = ops.conv3x3_wgrad(xin, g, cin, cout)
-            grads[wn], grads[bn] = dw, db
+            wgrad(wn, bn, xin, g, cin, cout)
             _, wd = packs.conv(wn, P[wn])
             # the conv input is a ReLU output when it came from a conv (mask here); when it came from a pool the
             # mask is applied by the pool backward below
@@ -235,7 +251,7 @@ class _OSVOSFunction(torch.autograd.Function):
     order; outputs: the 5 logit maps."""
 
     @staticmethod
-    def forward(ctx, packs: PackedWeights, with_side_out: bool, x: torch.Tensor, *params: torch.Tensor):
+    def forward(ctx, packs: PackedWeights, with_side_out: bool, inplace: bool, x: torch.Tensor, *params: torch.Tensor):
         P = dict(zip(PARAM_NAMES, params))
         outs, sv = forward(P, packs, x, with_side_out=with_side_out, keep=True)
         ctx.sv = sv
@@ -243,6 +259,7 @@ class _OSVOSFunction(torch.autograd.Function):
         ctx.P = P
         ctx.set_materialize_grads(False)
         ctx.with_side_out = with_side_out
+        ctx.inplace = inplace
         if not with_side_out:
             outs = [torch.empty(0, device=x.device) for _ in range(4)] + [outs[4]]
             ctx.mark_non_differentiable(*outs[:4])
@@ -255,9 +272,9 @@ class _OSVOSFunction(torch.autograd.Function):
         d = list(d_outs)
         if not ctx.with_side_out:
             d = [None] * 4 + [d[4]]
-        grads = backward(ctx.P, ctx.packs, ctx.sv, d)
+        grads = backward(ctx.P, ctx.packs, ctx.sv, d, inplace=ctx.inplace)
         ctx.sv = None  # free the activations
-        out = [None, None, None]
+        out = [None, None, None, None]
         for name in PARAM_NAMES:
             g = grads.get(name)
             p = ctx.P[name]
@@ -267,11 +284,12 @@ class _OSVOSFunction(torch.autograd.Function):
         return tuple(out)
 
 
-def run(packs: PackedWeights, params: Sequence[torch.Tensor], x: torch.Tensor, with_side_out: bool = True):
+def run(packs: PackedWeights, params: Sequence[torch.Tensor], x: torch.Tensor, with_side_out: bool = True,
+        inplace_grad: bool = False):
     """Forward through the HIP kernels.  With grad mode on and trainable parameters this records one
     autograd node; otherwise (inference) nothing is kept."""
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-        return list(_OSVOSFunction.apply(packs, with_side_out, x, *params))
+        return list(_OSVOSFunction.apply(packs, with_side_out, inplace_grad, x, *params))
     outs, _ = forward(dict(zip(PARAM_NAMES, params)), packs, x, with_side_out=with_side_out, keep=False)
     if not with_side_out:
         outs = [torch.empty(0, device=x.device) for _ in range(4)] + [outs[4]]

@@ -59,6 +59,51 @@ class Workspace:
 _WS = Workspace()
 
 
+# ------------------------------------------------------------------------------------------ profiling
+class OpProfiler:
+    """Optional per-call timing with HIP events on the launch stream (the current torch stream, which is
+    the stream every kernel here is launched on).  Off by default: bench.py turns it on for a few
+    iterations AFTER its timed region to obtain per-kernel durations for the roofline line."""
+
+    def __init__(self) -> None:
+        self.records = []  # (name, flops, bytes, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, nbytes, e0, e1 in self.records:
+            a = agg.setdefault(name, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a["calls"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += flops
+            a["bytes"] += nbytes
+        return agg
+
+
+_PROF: Optional[OpProfiler] = None
+
+
+def set_profiler(p: Optional[OpProfiler]) -> None:
+    global _PROF
+    _PROF = p
+
+
+def _pb():
+    if _PROF is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _pe(e0, name: str, flops: float = 0.0, nbytes: float = 0.0) -> None:
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    _PROF.records.append((name, float(flops), float(nbytes), e0, e1))
+
+
 # ------------------------------------------------------------------------------------------ layout
 def nchw_to_nhwc_bf16(x: torch.Tensor, c_pad: Optional[int] = None) -> torch.Tensor:
     _need(x, _F32, "nchw_to_nhwc_bf16")
@@ -109,7 +154,9 @@ def pack_conv3x3_weights(w: torch.Tensor, want_fwd: bool = True, want_dgrad: boo
     fwd = torch.empty(L.fosvos_packed_weight_elems(co, ci), dtype=_BF16, device=w.device) if want_fwd else None
     dgr = torch.empty(L.fosvos_packed_weight_elems(ci, co), dtype=_BF16, device=w.device) if want_dgrad else None
     dev, st = _ctx(w)
+    t0 = _pb()
     check(L.fosvos_pack_conv3x3_weights(w.data_ptr(), co, ci, _p(fwd), _p(dgr), dev, st), "pack_conv3x3_weights")
+    _pe(t0, "pack_weights", 0.0, w.numel() * 4 + 2 * ((fwd.numel() if fwd is not None else 0) + (dgr.numel() if dgr is not None else 0)))
     return fwd, dgr
 
 
@@ -122,8 +169,10 @@ def conv3x3_first_fwd(frame: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> 
     co = w.shape[0]
     y = torch.empty((n, h, wd, co), dtype=_BF16, device=frame.device)
     dev, st = _ctx(frame)
+    t0 = _pb()
     check(lib().fosvos_conv3x3_first_fwd(frame.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), n, h, wd, co, dev, st),
           "conv3x3_first_fwd")
+    _pe(t0, "conv1_1_fwd", 2.0 * n * h * wd * 27 * co, n * h * wd * (12 + 2 * co))
     return y
 
 
@@ -138,8 +187,10 @@ def conv3x3_first_wgrad(frame: torch.Tensor, dy: torch.Tensor) -> Tuple[torch.Te
     db = torch.empty((co,), dtype=_F32, device=frame.device)
     ws, wsn = _WS.get(L.fosvos_conv3x3_first_wgrad_workspace_bytes(n, h, wd, co), frame.device)
     dev, st = _ctx(frame)
+    t0 = _pb()
     check(L.fosvos_conv3x3_first_wgrad(frame.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), n, h, wd, co, ws, wsn,
                                        dev, st), "conv3x3_first_wgrad")
+    _pe(t0, "conv1_1_wgrad", 2.0 * n * h * wd * 27 * co, n * h * wd * (12 + 2 * co))
     return dw, db
 
 
@@ -160,8 +211,11 @@ def conv3x3_fwd(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
     flags = (CONV_RELU if relu else 0) | (CONV_OUT_F32 if out_f32 else 0)
     ws, wsn = _WS.get(L.fosvos_conv3x3_workspace_bytes(n, h, wd, ci, co), x.device)
     dev, st = _ctx(x)
+    t0 = _pb()
     check(L.fosvos_conv3x3_fwd(x.data_ptr(), w_packed.data_ptr(), _p(bias), y.data_ptr(), n, h, wd, ci, co, flags, ws, wsn,
                                dev, st), "conv3x3_fwd")
+    _pe(t0, "conv3x3_fwd", 2.0 * n * h * wd * 9 * ci * co,
+        n * h * wd * (2 * cx + (4 if out_f32 else 2) * co) + 2 * 9 * ci * co)
     return y
 
 
@@ -185,8 +239,11 @@ def conv3x3_dgrad(dy: torch.Tensor, w_dgrad_packed: torch.Tensor, ci: int, co: i
     dx = out if out is not None else torch.empty(shape, dtype=_BF16, device=dy.device)
     ws, wsn = _WS.get(L.fosvos_conv3x3_workspace_bytes(n, h, wd, co, ci), dy.device)
     dev, st = _ctx(dy)
+    t0 = _pb()
     check(L.fosvos_conv3x3_dgrad(dy.data_ptr(), w_dgrad_packed.data_ptr(), _p(relu_src), _p(addend), dx.data_ptr(), n, h, wd,
                                  ci, co, ws, wsn, dev, st), "conv3x3_dgrad")
+    _pe(t0, "conv3x3_dgrad", 2.0 * n * h * wd * 9 * ci * co,
+        n * h * wd * 2 * (cy + ci * (1 + (relu_src is not None) + (addend is not None))) + 2 * 9 * ci * co)
     return dx
 
 
@@ -208,8 +265,10 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ci: int, co: int, with_bias
     _need(dw, _F32, "conv3x3_wgrad dw")
     ws, wsn = _WS.get(L.fosvos_conv3x3_wgrad_workspace_bytes(n, h, wd, ci, co), x.device)
     dev, st = _ctx(x)
+    t0 = _pb()
     check(L.fosvos_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(db) if with_bias else None, n, h, wd, ci, co,
                                  1 if accumulate else 0, ws, wsn, dev, st), "conv3x3_wgrad")
+    _pe(t0, "conv3x3_wgrad", 2.0 * n * h * wd * 9 * ci * co, n * h * wd * 2 * (ci + dy.shape[3]) + 4 * 9 * ci * co)
     return dw, (db if with_bias else None)
 
 
@@ -219,7 +278,9 @@ def maxpool_fwd(x: torch.Tensor) -> torch.Tensor:
     n, h, w, c = x.shape
     y = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), dtype=_BF16, device=x.device)
     dev, st = _ctx(x)
+    t0 = _pb()
     check(lib().fosvos_maxpool2x2_ceil_fwd(x.data_ptr(), y.data_ptr(), n, h, w, c, dev, st), "maxpool2x2_ceil_fwd")
+    _pe(t0, "maxpool_fwd", 0.0, 2 * (x.numel() + y.numel()))
     return y
 
 
@@ -230,8 +291,10 @@ def maxpool_bwd(x: torch.Tensor, dy: torch.Tensor, relu_mask: bool = True) -> to
         raise ValueError("maxpool_bwd: dy shape mismatch")
     dx = torch.empty_like(x)
     dev, st = _ctx(x)
+    t0 = _pb()
     check(lib().fosvos_maxpool2x2_ceil_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n, h, w, c, 1 if relu_mask else 0,
                                            dev, st), "maxpool2x2_ceil_bwd")
+    _pe(t0, "maxpool_bwd", 0.0, 2 * (2 * x.numel() + dy.numel()))
     return dx
 
 
@@ -261,11 +324,13 @@ def head_fwd(side: Sequence[torch.Tensor], filt: Sequence[torch.Tensor], filt1: 
         f1_ptrs = [f.data_ptr() for f in filt1]
         _need(dsn_w, _F32, "head_fwd dsn_w"); _need(dsn_b, _F32, "head_fwd dsn_b")
     dev, st = _ctx(side[0])
+    t0 = _pb()
     check(lib().fosvos_head_fwd(ptr_array4([t.data_ptr() for t in side]), int_array4([t.shape[1] for t in side]),
                                 int_array4([t.shape[2] for t in side]), ptr_array4([t.data_ptr() for t in filt]),
                                 ptr_array4(f1_ptrs), _p(dsn_w) if with_side_out else None,
                                 _p(dsn_b) if with_side_out else None, fuse_w.data_ptr(), fuse_b.data_ptr(),
                                 fused.data_ptr(), ptr_array4(so_ptrs), n, H, W, dev, st), "head_fwd")
+    _pe(t0, "head_fwd", 2.0 * n * H * W * 256, 4 * (sum(t.numel() for t in side) + n * H * W * (5 if with_side_out else 1)))
     return fused, outs
 
 
@@ -294,11 +359,14 @@ def head_bwd(side: Sequence[torch.Tensor], filt: Sequence[torch.Tensor], filt1: 
     L = lib()
     ws, wsn = _WS.get(L.fosvos_head_bwd_workspace_bytes(n, H, W), dev_t)
     dev, st = _ctx(side[0])
+    t0 = _pb()
     check(L.fosvos_head_bwd(ptr_array4([t.data_ptr() for t in side]), int_array4([t.shape[1] for t in side]),
                             int_array4([t.shape[2] for t in side]), ptr_array4([t.data_ptr() for t in filt]),
                             ptr_array4(f1_ptrs), _p(dsn_w) if with_so else None, fuse_w.data_ptr(), _p(d_fused),
                             ptr_array4(dso_ptrs), ptr_array4([t.data_ptr() for t in d_side]), d_fuse_w.data_ptr(),
                             d_fuse_b.data_ptr(), _p(d_dsn_w), _p(d_dsn_b), n, H, W, ws, wsn, dev, st), "head_bwd")
+    _pe(t0, "head_bwd", 2.0 * n * H * W * 256, 4 * (sum(t.numel() for t in side) + n * H * W * (5 if with_so else 1)) +
+        2 * sum(t.numel() for t in d_side))
     return d_side, d_fuse_w, d_fuse_b, d_dsn_w, d_dsn_b
 
 
@@ -316,6 +384,8 @@ def cbce_loss(logits: torch.Tensor, label: torch.Tensor, size_average: bool = Tr
     # grow-only buffer may be re-used by the next op on the same stream (which is ordered after us)
     ws, wsn = _WS.get(L.fosvos_cbce_workspace_bytes(logits.numel()), logits.device)
     dev, st = _ctx(logits)
+    t0 = _pb()
     check(L.fosvos_cbce_loss(logits.data_ptr(), label.data_ptr(), logits.numel(), 1 if size_average else 0,
                              float(grad_scale), loss.data_ptr(), _p(grad), ws, wsn, dev, st), "cbce_loss")
+    _pe(t0, "cbce_loss", 0.0, logits.numel() * (16 if want_grad else 12))
     return loss, grad

@@ -53,6 +53,9 @@ class OSVOS_VGG(nn.Module):
         self.fuse = nn.Conv2d(64, 1, kernel_size=1, padding=0)
 
         self._packs = engine.PackedWeights()  # bf16 MFMA images of the weights, rebuilt when a master changes
+        # Opt-in for training loops that call ``loss.backward()`` (never ``torch.autograd.grad``): let the wgrad
+        # kernels add straight into existing ``p.grad`` tensors instead of handing autograd a fresh tensor to add.
+        self.accumulate_grads_in_place = False
 
         log.info("Initializing weights")
         self._initialize_weights(pretrained)
@@ -62,7 +65,8 @@ class OSVOS_VGG(nn.Module):
         """list of 5 logit maps [N,1,H,W]: the 4 side outputs then the fused output."""
         sd = dict(self.named_parameters())
         params = [sd[name] for name in engine.PARAM_NAMES]
-        return engine.run(self._packs, params, x, with_side_out=True)
+        return engine.run(self._packs, params, x, with_side_out=True,
+                          inplace_grad=getattr(self, 'accumulate_grads_in_place', False))
 
     def __getstate__(self):
         state = self.__dict__.copy()

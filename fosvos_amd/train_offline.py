@@ -68,6 +68,7 @@ def _train(net_provider: NetworkProvider, data_loader_train, data_loader_test, o
            is_testing_while_training: bool, test_every_n: int) -> dict:
     log.info('Start of offline training')
     net = net_provider.network
+    net.accumulate_grads_in_place = True  # this loop only ever calls loss.backward()
     world = parallel.world_size() if data_parallel else 1
     local_accum = parallel.split_accumulation(avg_grad_every_n, world)
     flat = parallel.FlatGrads(net.parameters()) if world > 1 else None

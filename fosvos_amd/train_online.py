@@ -76,6 +76,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
            start_epoch: int, n_epochs: int, avg_grad_every_n: int, snapshot_every_n: int) -> dict:
     log.info('Start of Online Training, sequence: ' + seq_name)
     net = net_provider.network
+    net.accumulate_grads_in_place = True  # this loop only ever calls loss.backward()
     world = parallel.world_size() if data_parallel else 1
     local_accum = parallel.split_accumulation(avg_grad_every_n, world)
     flat = parallel.FlatGrads(net.parameters()) if world > 1 else None

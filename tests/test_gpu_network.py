@@ -173,6 +173,24 @@ def test_online_loop_vs_golden(golden):
                 assert torch.equal(p.detach().cpu(), sd[name])
 
 
+def test_inplace_grad_accumulation_matches_autograd():
+    """accumulate_grads_in_place (wgrad kernels add into p.grad) gives the same gradients as letting autograd
+    accumulate, bit for bit for a single backward and to fp32 rounding for two."""
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    x, gt = O.synthetic_frame(1, 40, 70, seed=31)
+    res = []
+    for inplace in (False, True):
+        net, _ = make_net(12)
+        net.accumulate_grads_in_place = inplace
+        for _ in range(2):
+            cbce(net(x.to(DEV))[-1], gt.to(DEV), size_average=False).backward()
+        res.append({n_: p.grad.clone() for n_, p in net.named_parameters() if p.grad is not None})
+    assert res[0].keys() == res[1].keys()
+    for k_ in res[0]:
+        a, b = res[0][k_], res[1][k_]
+        assert (a - b).abs().max().item() <= 1e-6 * a.abs().max().item() + 1e-30, k_
+
+
 def test_offline_loop_vs_golden(golden):
     from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
     from util.network_provider import VGGOfflineProvider
