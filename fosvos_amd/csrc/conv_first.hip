@@ -11,12 +11,12 @@ using namespace fosvos;
 
 namespace {
 constexpr int CO = 64;     // the only instantiation the model needs (checked at the entry point)
-constexpr int TW = 64;     // pixels per wave (one image-row segment)
+constexpr int PX = 4;      // consecutive pixels per thread
+constexpr int TW = 8 * PX; // pixels per wave (one image-row segment)
 constexpr int ROWS = 4;    // waves per block = image rows per block
-constexpr int PX = 8;      // consecutive pixels per thread
 
 // ---------------------------------------------------------------------------------------- forward
-// Block = 4 waves = 4 image rows x 64 pixels.  Lane l of a wave owns pixels 8*(l/8)..+7 of the
+// Block = 4 waves = 4 image rows x 32 pixels.  Lane l of a wave owns pixels 4*(l/8)..+3 of the
 // segment and output channels 8*(l%8)..+7, so the 8 lanes of a pixel store one full 128-byte
 // NHWC pixel.  Weights live in LDS as [27][64] fp32 (each lane reads its 8 channels as 2 x 16 B:
 // the 8 channel groups cover one 256-byte bank row, conflict-free); the 6 x 66 input halo rows
@@ -63,15 +63,13 @@ __global__ __launch_bounds__(256) void k_first_fwd(const float *__restrict__ fra
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            // inputs x = 8*pg-1 .. 8*pg+8 of halo row (wave + ky): LDS x index = 8*pg + 3 .. 8*pg + 12
+            // inputs x = 4*pg-1 .. 4*pg+4 of halo row (wave + ky): LDS x index = 4*pg + 3 .. 4*pg + 8
             float in[PX + 2];
-            const float *row = &s_in[c][wave + ky][pg * 8];
+            const float *row = &s_in[c][wave + ky][pg * 4];
             const float4 a = *reinterpret_cast<const float4 *>(row);       // idx 0..3
             const float4 b = *reinterpret_cast<const float4 *>(row + 4);   // idx 4..7
-            const float4 d = *reinterpret_cast<const float4 *>(row + 8);   // idx 8..11
-            const float e = row[12];
-            in[0] = a.w; in[1] = b.x; in[2] = b.y; in[3] = b.z; in[4] = b.w;
-            in[5] = d.x; in[6] = d.y; in[7] = d.z; in[8] = d.w; in[9] = e;
+            const float e = row[8];
+            in[0] = a.w; in[1] = b.x; in[2] = b.y; in[3] = b.z; in[4] = b.w; in[5] = e;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int k = c * 9 + ky * 3 + kx;
@@ -88,7 +86,7 @@ __global__ __launch_bounds__(256) void k_first_fwd(const float *__restrict__ fra
     }
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
-        const int gx = x0 + pg * 8 + p;
+        const int gx = x0 + pg * PX + p;
         if (gx < W) {
             float o[8];
 #pragma unroll
@@ -100,56 +98,79 @@ __global__ __launch_bounds__(256) void k_first_fwd(const float *__restrict__ fra
 
 // ---------------------------------------------------------------------------------------- wgrad
 // dw[co][ci][tap] = sum_px dy[px][co] * in[ci][px + tap];  db[co] = sum_px dy[px][co].
-// Block = 4 waves = one image row x 256 pixels; wave q sweeps its own 64 pixels.  Lane = output
-// channel, so dy loads are 128 contiguous bytes per pixel and the 27 input values of a pixel are
-// wave-uniform (the compiler keeps them on the scalar path: v_fmac with an SGPR operand).
+// Block = 4 waves = 8 image rows x 256 pixels; wave q sweeps its own 64 columns.  Lane = output
+// channel, so dy loads are 128 contiguous bytes per pixel; the frame tile sits in LDS and the input
+// values of a 4-pixel group are wave-uniform broadcast reads (27 ds_read_b128-class reads per 108 FMAs).
 // Each block writes one slab of Co*28 floats; k_first_reduce sums the slabs in index order.
 constexpr int WG_PIX = 256;
 constexpr int WG_ROWS = 8;  // image rows swept by one block
 
 __global__ __launch_bounds__(256) void k_first_wgrad(const float *__restrict__ frame, const uint16_t *__restrict__ dy,
                                                       float *__restrict__ slabs, int H, int W) {
+    // frame tile with a one-pixel halo, zero outside the image; LDS x index 0 <-> image x0-4 so that the
+    // 4-pixel groups below are 16-byte aligned
+    __shared__ __attribute__((aligned(16))) float s_in[3][WG_ROWS + 2][WG_PIX + 8];
+    __shared__ float s_red[4][28][CO];
     const int n = blockIdx.z;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int co = threadIdx.x & 63;
-    const int xs = blockIdx.x * WG_PIX + q * 64;
+    const int x0 = blockIdx.x * WG_PIX, y0 = blockIdx.y * WG_ROWS;
     const int64_t plane = (int64_t)H * W;
     const float *fr = frame + (int64_t)n * 3 * plane;
+    for (int i = threadIdx.x; i < 3 * (WG_ROWS + 2) * (WG_PIX + 8); i += 256) {
+        const int xx = i % (WG_PIX + 8);
+        const int r = (i / (WG_PIX + 8)) % (WG_ROWS + 2);
+        const int c = i / ((WG_PIX + 8) * (WG_ROWS + 2));
+        const int gy = y0 + r - 1, gx = x0 + xx - 4;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = fr[c * plane + (int64_t)gy * W + gx];
+        s_in[c][r][xx] = v;
+    }
+    __syncthreads();
     float acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.f;
     float accb = 0.f;
-    const int xe = min(xs + 64, W);
-    const int gy_end = min((int)(blockIdx.y + 1) * WG_ROWS, H);
-    for (int gy = blockIdx.y * WG_ROWS; gy < gy_end; ++gy)
-    for (int x = xs; x < xe; ++x) {
-        const float g = bf2f(dy[(((int64_t)n * H + gy) * W + x) * CO + co]);
-        accb += g;
+    const int rows = min(WG_ROWS, H - y0);
+    for (int r = 0; r < rows; ++r) {
+        const uint16_t *dyr = dy + (((int64_t)n * H + y0 + r) * W) * CO + co;
+        for (int xb = 0; xb < 16; ++xb) {
+            const int xl = q * 64 + xb * 4;  // tile-local x of the first of 4 pixels
+            const int gx = x0 + xl;
+            if (gx >= W) break;
+            float g[4];
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+            for (int p = 0; p < 4; ++p) g[p] = (gx + p < W) ? bf2f(dyr[(int64_t)(gx + p) * CO]) : 0.f;
+            accb += (g[0] + g[1]) + (g[2] + g[3]);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int yy = gy + ky - 1;
-                const bool rowok = yy >= 0 && yy < H;
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int xx = x + kx - 1;
-                    float v = 0.f;
-                    if (rowok && xx >= 0 && xx < W) v = fr[c * plane + (int64_t)yy * W + xx];
-                    acc[c * 9 + ky * 3 + kx] += g * v;
+                for (int ky = 0; ky < 3; ++ky) {
+                    // wave-uniform address: LDS broadcast reads of inputs x-1 .. x+4
+                    const float *row = &s_in[c][r + ky][xl];
+                    const float4 a = *reinterpret_cast<const float4 *>(row);
+                    const float4 b = *reinterpret_cast<const float4 *>(row + 4);
+                    const float e = row[8];
+                    const float in[6] = {a.w, b.x, b.y, b.z, b.w, e};
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float t = acc[c * 9 + ky * 3 + kx];
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) t += g[p] * in[p + kx];
+                        acc[c * 9 + ky * 3 + kx] = t;
+                    }
                 }
-            }
+        }
     }
     // combine the 4 waves through LDS in wave order (fixed order => deterministic)
-    __shared__ float s[4][28][CO];
 #pragma unroll
-    for (int k = 0; k < 27; ++k) s[q][k][co] = acc[k];
-    s[q][27][co] = accb;
+    for (int k = 0; k < 27; ++k) s_red[q][k][co] = acc[k];
+    s_red[q][27][co] = accb;
     __syncthreads();
     const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     for (int i = threadIdx.x; i < 28 * CO; i += 256) {
         const int k = i / CO, c = i % CO;
-        slabs[(int64_t)blk * 28 * CO + i] = (s[0][k][c] + s[1][k][c]) + (s[2][k][c] + s[3][k][c]);
+        slabs[(int64_t)blk * 28 * CO + i] = (s_red[0][k][c] + s_red[1][k][c]) + (s_red[2][k][c] + s_red[3][k][c]);
     }
 }
 

@@ -33,6 +33,9 @@ struct ConvArgs {
     int N, H, W, Cin, Cout, Co_pad;
     int tiles_x, tiles_y;
     unsigned flags;
+    int k_splits;      // > 1: blockIdx.z owns a range of K chunks and writes raw fp32 partials
+    int chunks_per_split;
+    float *partial;    // [k_splits][N*H*W][Cout] fp32 when k_splits > 1
 };
 
 template <int TH_, int TW_, int BN_, int WM_, int WN_>
@@ -114,8 +117,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_igemm(const ConvArgs a) {
     const int b_base = (lane >> 4) * T::BN + wn * T::WAVE_N + (lane & 15);
 
     const int n_chunks = Cin >> 5;
-    for (int cc = 0; cc < n_chunks; ++cc) {
-        if (cc > 0) __syncthreads();
+    const int c_begin = a.k_splits > 1 ? blockIdx.z * a.chunks_per_split : 0;
+    const int c_end = a.k_splits > 1 ? min(c_begin + a.chunks_per_split, n_chunks) : n_chunks;
+    for (int cc = c_begin; cc < c_end; ++cc) {
+        if (cc > c_begin) __syncthreads();
         // ---- stage A (input halo tile, zero outside the image)
 #pragma unroll
         for (int it = 0; it < T::A_IT; ++it) {
@@ -157,6 +162,22 @@ __global__ __launch_bounds__(256) void k_conv3x3_igemm(const ConvArgs a) {
 
     // ---- epilogue.  C/D layout: acc[i][j][r] = out[pixel wm*WAVE_M + 16 i + 4 (lane>>4) + r][channel wn*WAVE_N + 16 j + (lane&15)]
     const int q = lane >> 4, cl = lane & 15;
+    if (a.k_splits > 1) {  // split-K: raw fp32 partial sums, finished by k_splitk_epilogue
+        float *po = a.partial + (int64_t)blockIdx.z * a.N * H * W * a.Cout;
+#pragma unroll
+        for (int j = 0; j < T::NF; ++j) {
+            const int co = n0 + wn * T::WAVE_N + j * 16 + cl;
+#pragma unroll
+            for (int i = 0; i < T::MF; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pix = wm * T::WAVE_M + i * 16 + q * 4 + r;
+                    const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
+                    if (gy < H && gx < W) po[(((int64_t)n * H + gy) * W + gx) * a.Cout + co] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     if (OUT_F32) {
         float *yo = reinterpret_cast<float *>(a.y);
 #pragma unroll
@@ -224,50 +245,151 @@ __global__ __launch_bounds__(256) void k_conv3x3_igemm(const ConvArgs a) {
     }
 }
 
-template <class T, bool OUT_F32>
-int launch(const ConvArgs &a0, hipStream_t st) {
-    ConvArgs a = a0;
-    a.tiles_x = (int)cdiv(a.W, T::TW);
-    a.tiles_y = (int)cdiv(a.H, T::TH);
-    const int64_t tiles = (int64_t)a.tiles_x * a.tiles_y * a.N;
-    FOSVOS_REQUIRE(tiles <= 0x7fffffff && a.Cout % T::BN == 0, FOSVOS_E_SHAPE, "conv3x3: tile grid");
-    static bool attr_done = false;  // benign race: idempotent
-    if (!attr_done && T::LDS_BYTES > 64 * 1024) {
-        FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_igemm<T, OUT_F32>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-        attr_done = true;
+// Finish a split-K convolution: out = epilogue(sum_z partial[z] + bias).  One thread = 8 channels of a pixel.
+__global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int64_t total8) {
+    const int groups = a.Cout >> 3;
+    const int64_t plane = (int64_t)a.N * a.H * a.W * a.Cout;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+        const int g = (int)(i % groups);
+        const int64_t off = i * 8;
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        for (int z = 0; z < a.k_splits; ++z) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(a.partial + z * plane + off);
+            const float4 v1 = *reinterpret_cast<const float4 *>(a.partial + z * plane + off + 4);
+            f[0] += v0.x; f[1] += v0.y; f[2] += v0.z; f[3] += v0.w;
+            f[4] += v1.x; f[5] += v1.y; f[6] += v1.z; f[7] += v1.w;
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += a.bias[g * 8 + e];
+        }
+        if (a.flags & FOSVOS_CONV_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+        }
+        if (a.flags & FOSVOS_CONV_OUT_F32) {
+            float *yo = reinterpret_cast<float *>(a.y) + off;
+            *reinterpret_cast<float4 *>(yo) = make_float4(f[0], f[1], f[2], f[3]);
+            *reinterpret_cast<float4 *>(yo + 4) = make_float4(f[4], f[5], f[6], f[7]);
+            continue;
+        }
+        if (a.relu_src || a.addend) {
+            // same rounding sequence as the fused epilogue: round, mask, add, round
+            uint4 v = pack8(f);
+            unpack8(v, f);
+            if (a.relu_src) {
+                float m[8];
+                unpack8(*reinterpret_cast<const uint4 *>(a.relu_src + off), m);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = m[e] > 0.f ? f[e] : 0.f;
+            }
+            if (a.addend) {
+                float ad[8];
+                unpack8(*reinterpret_cast<const uint4 *>(a.addend + off), ad);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += ad[e];
+            }
+        }
+        *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(a.y) + off) = pack8(f);
     }
-    hipLaunchKernelGGL((k_conv3x3_igemm<T, OUT_F32>), dim3((unsigned)tiles, (unsigned)(a.Cout / T::BN)), dim3(256),
-                       T::LDS_BYTES, st, a);
-    FOSVOS_LAUNCH_CHECK();
-    return FOSVOS_OK;
 }
 
 // tile configurations
-using TileBig = Tile<8, 32, 64, 4, 1>;    // 256 px x 64 ch: stages 1-3
-using TileMid = Tile<8, 16, 64, 2, 2>;    // 128 px x 64 ch: stage 4 (60 x 107)
-using TileSmall = Tile<4, 16, 64, 2, 2>;  //  64 px x 64 ch: stage 5 (30 x 54)
+using TileBig = Tile<8, 32, 64, 4, 1>;    // 256 px x 64 ch
+using TileMid = Tile<8, 16, 64, 2, 2>;    // 128 px x 64 ch
+using TileSmall = Tile<4, 16, 64, 2, 2>;  //  64 px x 64 ch
 using TileSide = Tile<8, 32, 16, 4, 1>;   // 256 px x 16 ch: side_prep at large maps
 using TileSideS = Tile<4, 16, 16, 4, 1>;  //  64 px x 16 ch: side_prep at small maps
 
-int dispatch(const ConvArgs &a, hipStream_t st) {
+enum TileId { kBig, kMid, kSmall, kSide, kSideS };
+
+struct ConvPlan {
+    TileId tile;
+    int k_splits, chunks_per_split;
+    size_t workspace_bytes;
+};
+
+// Pick the tile and the K split: prefer the largest pixel tile that still yields >= kMinBlocks workgroups
+// (256 CUs x 2 resident workgroups); when even the smallest tile cannot, split the K chunks over blockIdx.z
+// so that weights are streamed once per pixel tile and the chip is filled.
+constexpr int kMinBlocks = 512;
+
+ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
+    ConvPlan p{};
+    const int n_chunks = roundup(in_ch, 32) / 32;
+    const int64_t pixels = (int64_t)N * H * W;
+    auto blocks = [&](int th, int tw, int bn) { return cdiv(W, tw) * cdiv(H, th) * N * (int64_t)(out_ch / bn); };
+    int64_t nb;
+    if (out_ch % 64 == 0) {
+        if (blocks(8, 32, 64) >= kMinBlocks) { p.tile = kBig; nb = blocks(8, 32, 64); }
+        else if (blocks(8, 16, 64) >= kMinBlocks * 3 / 4) { p.tile = kMid; nb = blocks(8, 16, 64); }
+        else if (pixels >= 4096) { p.tile = kMid; nb = blocks(8, 16, 64); }
+        else { p.tile = kMid; nb = blocks(8, 16, 64); }
+    } else {
+        if (pixels >= 256 * 256) { p.tile = kSide; nb = blocks(8, 32, 16); }
+        else { p.tile = kSideS; nb = blocks(4, 16, 16); }
+    }
+    int ks = 1;
+    if (nb < kMinBlocks * 3 / 4) {
+        ks = (int)cdiv(kMinBlocks, nb);
+        if (ks > n_chunks) ks = n_chunks;
+        if (ks > 16) ks = 16;
+    }
+    p.chunks_per_split = (int)cdiv(n_chunks, ks);
+    p.k_splits = (int)cdiv(n_chunks, p.chunks_per_split);
+    p.workspace_bytes = p.k_splits > 1 ? (size_t)p.k_splits * pixels * out_ch * sizeof(float) : 0;
+    return p;
+}
+
+template <class T, bool OUT_F32>
+int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st) {
+    ConvArgs a = a0;
+    a.tiles_x = (int)cdiv(a.W, T::TW);
+    a.tiles_y = (int)cdiv(a.H, T::TH);
+    a.k_splits = plan.k_splits;
+    a.chunks_per_split = plan.chunks_per_split;
+    const int64_t tiles = (int64_t)a.tiles_x * a.tiles_y * a.N;
+    FOSVOS_REQUIRE(tiles <= 0x7fffffff && a.Cout % T::BN == 0, FOSVOS_E_SHAPE, "conv3x3: tile grid");
+    hipLaunchKernelGGL((k_conv3x3_igemm<T, OUT_F32>),
+                       dim3((unsigned)tiles, (unsigned)(a.Cout / T::BN), (unsigned)plan.k_splits), dim3(256),
+                       T::LDS_BYTES, st, a);
+    FOSVOS_LAUNCH_CHECK();
+    if (plan.k_splits > 1) {
+        const int64_t total8 = (int64_t)a.N * a.H * a.W * (a.Cout / 8);
+        int64_t g = cdiv(total8, 256);
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)g), dim3(256), 0, st, a, total8);
+        FOSVOS_LAUNCH_CHECK();
+    }
+    return FOSVOS_OK;
+}
+
+int dispatch(ConvArgs a, int in_ch, void *workspace, size_t workspace_bytes, hipStream_t st) {
     const bool f32 = (a.flags & FOSVOS_CONV_OUT_F32) != 0;
-    const int64_t pixels = (int64_t)a.N * a.H * a.W;
-    if (a.Cout % 64 == 0) {
+    if (a.Cout % 64 != 0) {
+        FOSVOS_REQUIRE(a.Cout == 16, FOSVOS_E_SHAPE, "conv3x3: output channels must be 16 or a multiple of 64 (got %d)",
+                       a.Cout);
+        FOSVOS_REQUIRE(a.relu_src == nullptr && a.addend == nullptr, FOSVOS_E_ARG,
+                       "conv3x3: 16-channel output has no mask/add epilogue");
+    } else {
         FOSVOS_REQUIRE(!f32, FOSVOS_E_ARG, "conv3x3: fp32 output is only built for 16-channel outputs");
-        const int64_t blocks_big = cdiv(a.W, 32) * cdiv(a.H, 8) * a.N * (a.Cout / 64);
-        const int64_t blocks_mid = cdiv(a.W, 16) * cdiv(a.H, 8) * a.N * (a.Cout / 64);
-        if (blocks_big >= 512) return launch<TileBig, false>(a, st);
-        if (blocks_mid >= 384) return launch<TileMid, false>(a, st);
-        return launch<TileSmall, false>(a, st);
     }
-    FOSVOS_REQUIRE(a.Cout == 16, FOSVOS_E_SHAPE, "conv3x3: output channels must be 16 or a multiple of 64 (got %d)",
-                   a.Cout);
-    FOSVOS_REQUIRE(a.relu_src == nullptr && a.addend == nullptr, FOSVOS_E_ARG, "conv3x3: 16-channel output has no mask/add epilogue");
-    if (pixels >= 256 * 256) {
-        return f32 ? launch<TileSide, true>(a, st) : launch<TileSide, false>(a, st);
+    const ConvPlan plan = make_plan(a.N, a.H, a.W, in_ch, a.Cout);
+    if (plan.k_splits > 1) {
+        FOSVOS_REQUIRE(workspace && workspace_bytes >= plan.workspace_bytes, FOSVOS_E_WORKSPACE,
+                       "conv3x3: split-K needs %zu workspace bytes, got %zu", plan.workspace_bytes, workspace_bytes);
+        a.partial = reinterpret_cast<float *>(workspace);
     }
-    return f32 ? launch<TileSideS, true>(a, st) : launch<TileSideS, false>(a, st);
+    switch (plan.tile) {
+        case kBig: return launch<TileBig, false>(a, plan, st);
+        case kMid: return launch<TileMid, false>(a, plan, st);
+        case kSmall: return launch<TileSmall, false>(a, plan, st);
+        case kSide: return f32 ? launch<TileSide, true>(a, plan, st) : launch<TileSide, false>(a, plan, st);
+        case kSideS: return f32 ? launch<TileSideS, true>(a, plan, st) : launch<TileSideS, false>(a, plan, st);
+    }
+    return fail(FOSVOS_E_ARG, "conv3x3: bad plan");
 }
 
 int check_common(const void *x, const void *w, const void *y, int N, int H, int W, int in_ch, int out_ch,
@@ -282,27 +404,31 @@ int check_common(const void *x, const void *w, const void *y, int N, int H, int 
 }
 }  // namespace
 
-extern "C" size_t fosvos_conv3x3_workspace_bytes(int, int, int, int, int) { return 0; }
+extern "C" size_t fosvos_conv3x3_workspace_bytes(int N, int H, int W, int in_ch, int out_ch) {
+    if (N <= 0 || H <= 0 || W <= 0 || in_ch <= 0 || out_ch <= 0 || (out_ch % 64 != 0 && out_ch != 16)) return 0;
+    return make_plan(N, H, W, in_ch, out_ch).workspace_bytes;
+}
 
 extern "C" int fosvos_conv3x3_fwd(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int N, int H,
-                                  int W, int Ci, int Co, unsigned flags, void *, size_t, int device, void *stream) {
+                                  int W, int Ci, int Co, unsigned flags, void *workspace, size_t workspace_bytes,
+                                  int device, void *stream) {
     if (int rc = check_common(x, w_packed, y, N, H, W, Ci, Co, "conv3x3_fwd")) return rc;
     FOSVOS_REQUIRE((flags & ~(FOSVOS_CONV_RELU | FOSVOS_CONV_OUT_F32)) == 0, FOSVOS_E_ARG, "conv3x3_fwd: unknown flags 0x%x", flags);
     FOSVOS_ENTER(device);
     ConvArgs a{};
     a.x = x; a.w = w_packed; a.bias = bias; a.relu_src = nullptr; a.addend = nullptr; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Cin = roundup(Ci, 32); a.Cout = Co; a.Co_pad = roundup(Co, 16); a.flags = flags;
-    return dispatch(a, (hipStream_t)stream);
+    return dispatch(a, Ci, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int fosvos_conv3x3_dgrad(const uint16_t *dy, const uint16_t *w_dgrad_packed, const uint16_t *relu_src,
-                                    const uint16_t *addend, uint16_t *dx, int N, int H, int W, int Ci, int Co, void *,
-                                    size_t, int device, void *stream) {
+                                    const uint16_t *addend, uint16_t *dx, int N, int H, int W, int Ci, int Co,
+                                    void *workspace, size_t workspace_bytes, int device, void *stream) {
     // contraction over the forward op's output channels (Co), result has its input channels (Ci)
     if (int rc = check_common(dy, w_dgrad_packed, dx, N, H, W, Co, Ci, "conv3x3_dgrad")) return rc;
     FOSVOS_ENTER(device);
     ConvArgs a{};
     a.x = dy; a.w = w_dgrad_packed; a.bias = nullptr; a.relu_src = relu_src; a.addend = addend; a.y = dx;
     a.N = N; a.H = H; a.W = W; a.Cin = roundup(Co, 32); a.Cout = Ci; a.Co_pad = roundup(Ci, 16); a.flags = 0;
-    return dispatch(a, (hipStream_t)stream);
+    return dispatch(a, Co, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -9,7 +9,7 @@
 // Geometry per scale s (f = 2^(s+1), k = 2f): deconv output size (h+1)*f; output pixel Yo receives
 // input rows i1 = Yo/f (tap ky = Yo%f) and i0 = i1-1 (tap ky+f); the crop removes
 // top = floor(((h+1)f - H)/2) leading rows (same for columns).  Upscale weights enter as their
-// diagonal: filt[s] = [16][k][k] (one filter per channel), filt1[s] = [k][k].
+// diagonal, channel fastest: filt[s] = [k][k][16] (one k x k filter per channel), filt1[s] = [k][k].
 #include "common.hpp"
 
 using namespace fosvos;
@@ -86,11 +86,17 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadPtrs p, HeadGeom g, const 
                         const float4 t = sp[q];
                         v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
                     }
-                    const float *fp = fl + ky * k + kx;
+                    const float4 *fp = reinterpret_cast<const float4 *>(fl + (ky * k + kx) * 16);
+                    float fv[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 t = fp[q];
+                        fv[4 * q] = t.x; fv[4 * q + 1] = t.y; fv[4 * q + 2] = t.z; fv[4 * q + 3] = t.w;
+                    }
                     float score = 0.f;
 #pragma unroll
                     for (int c = 0; c < 16; ++c) {
-                        out += s_fw[16 * s + c] * (fp[c * k * k] * v[c]);
+                        out += s_fw[16 * s + c] * (fv[c] * v[c]);
                         if (WITH_SIDE_OUT) score += s_dw[16 * s + c] * v[c];
                     }
                     if (WITH_SIDE_OUT) so_acc += (score + dsn_b[s]) * p.filt1[s][ky * k + kx];
@@ -103,67 +109,129 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadPtrs p, HeadGeom g, const 
 }
 
 // ---------------------------------------------------------------------------------------- backward
-// Per scale: one thread per (low-res pixel, channel); the 16 lanes of a pixel share the
-// 2f x 2f window of upstream gradients (broadcast loads) and each applies its own filter:
-//   T_c = sum_window filt[c][ky][kx] * d_fused[Y,X]      G = sum_window filt1[ky][kx] * d_side_out[Y,X]
+// Per scale S (f = 2^(S+1), k = 2f): a workgroup owns a TI x TJ tile of low-res pixels.  It stages the
+// (TI+1)f x (TJ+1)f window of upstream gradients (zero outside the image) and the whole [k][k][16]
+// filter in LDS, then thread (pixel p, channel c) evaluates
+//   T_c = sum_window filt[ky][kx][c] * d_fused[Y,X]      G = sum_window filt1[ky][kx] * d_side_out[Y,X]
 //   d_side[c]  = fuse_w[16s+c] * T_c + dsn_w[s][c] * G
 //   d_fuse_w[16s+c] += side[c] * T_c;  d_dsn_w[s][c] += side[c] * G;  d_dsn_b[s] += G
+// from LDS only (filter reads: 16 consecutive floats per pixel group; window reads: broadcasts).
 // Block partials go to the workspace as slabs [block][3][16]; k_head_finish sums them in order.
-template <bool WITH_SIDE_OUT>
+template <int S> struct HeadTile;
+template <> struct HeadTile<0> { static constexpr int TI = 8, TJ = 32; };
+template <> struct HeadTile<1> { static constexpr int TI = 4, TJ = 16; };
+template <> struct HeadTile<2> { static constexpr int TI = 4, TJ = 4; };
+template <> struct HeadTile<3> { static constexpr int TI = 2, TJ = 8; };
+
+template <int S, bool WITH_SIDE_OUT>
 __global__ __launch_bounds__(256) void k_head_bwd_scale(const float *__restrict__ side, const float *__restrict__ filt,
                                                          const float *__restrict__ filt1,
                                                          const float *__restrict__ fuse_w16,
                                                          const float *__restrict__ dsn_w16,
                                                          const float *__restrict__ d_fused,
                                                          const float *__restrict__ d_so, uint16_t *__restrict__ d_side,
-                                                         float *__restrict__ slabs, int s, int hs, int ws, int top,
-                                                         int left, int H, int W, int64_t total /* N*hs*ws*16 */) {
-    const int f = 2 << s, k = 4 << s;
-    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int c = threadIdx.x & 15;
-    float T = 0.f, G = 0.f, sv = 0.f;
-    const bool active = idx < total;
-    if (active) {
-        const int64_t pix = idx >> 4;
-        const int j = (int)(pix % ws);
-        const int64_t r = pix / ws;
-        const int i = (int)(r % hs);
-        const int64_t n = r / hs;
-        const float *fc = filt + (int64_t)c * k * k;
-        const int Y0 = i * f - top, X0 = j * f - left;
-        const int ky_lo = max(0, -Y0), ky_hi = min(k, H - Y0);
-        const int kx_lo = max(0, -X0), kx_hi = min(k, W - X0);
-        for (int ky = ky_lo; ky < ky_hi; ++ky) {
-            const int64_t rowoff = (n * H + (Y0 + ky)) * W + X0;
-            for (int kx = kx_lo; kx < kx_hi; ++kx) {
-                if (d_fused) T += fc[ky * k + kx] * d_fused[rowoff + kx];
-                if (WITH_SIDE_OUT) G += filt1[ky * k + kx] * d_so[rowoff + kx];
+                                                         float *__restrict__ slabs, int hs, int ws, int top, int left,
+                                                         int H, int W) {
+    constexpr int f = 2 << S, k = 4 << S;
+    constexpr int TI = HeadTile<S>::TI, TJ = HeadTile<S>::TJ;
+    constexpr int WR = (TI + 1) * f, WC = (TJ + 1) * f;
+    extern __shared__ __attribute__((aligned(16))) float smem_h[];
+    float *sF = smem_h;                 // [k*k][16]
+    float *sW = sF + k * k * 16;        // [WR][WC] window of d_fused
+    float *sW1 = sW + WR * WC;          // [WR][WC] window of d_side_out   (WITH_SIDE_OUT)
+    float *sF1 = sW1 + (WITH_SIDE_OUT ? WR * WC : 0);  // [k*k]            (WITH_SIDE_OUT)
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z, i0 = blockIdx.y * TI, j0 = blockIdx.x * TJ;
+    const int Y0 = i0 * f - top, X0 = j0 * f - left;
+    for (int e = tid; e < k * k * 4; e += 256)
+        reinterpret_cast<float4 *>(sF)[e] = reinterpret_cast<const float4 *>(filt)[e];
+    for (int e = tid; e < WR * WC; e += 256) {
+        const int r = e / WC, cidx = e - r * WC;
+        const int Y = Y0 + r, X = X0 + cidx;
+        const bool ok = Y >= 0 && Y < H && X >= 0 && X < W;
+        const int64_t off = ((int64_t)n * H + Y) * W + X;
+        sW[e] = (ok && d_fused) ? d_fused[off] : 0.f;
+        if (WITH_SIDE_OUT) sW1[e] = ok ? d_so[off] : 0.f;
+    }
+    if (WITH_SIDE_OUT)
+        for (int e = tid; e < k * k; e += 256) sF1[e] = filt1[e];
+    __syncthreads();
+    const int c = tid & 15, pl = tid >> 4;
+    const float fw = fuse_w16[c];
+    const float dw = WITH_SIDE_OUT ? dsn_w16[c] : 0.f;
+    float a = 0.f, b = 0.f, g = 0.f;
+    for (int p = pl; p < TI * TJ; p += 16) {
+        const int il = p / TJ, jl = p - il * TJ;
+        const int i = i0 + il, j = j0 + jl;
+        if (i >= hs || j >= ws) continue;
+        float T = 0.f, G = 0.f;
+        const float *wp = sW + il * f * WC + jl * f;
+        const float *wp1 = sW1 + il * f * WC + jl * f;
+#pragma unroll 4
+        for (int ky = 0; ky < k; ++ky) {
+#pragma unroll 8
+            for (int kx = 0; kx < k; ++kx) {
+                T += sF[(ky * k + kx) * 16 + c] * wp[ky * WC + kx];
+                if (WITH_SIDE_OUT) G += sF1[ky * k + kx] * wp1[ky * WC + kx];
             }
         }
-        sv = side[idx];
-        const float ds = fuse_w16[c] * T + (WITH_SIDE_OUT ? dsn_w16[c] * G : 0.f);
-        // padded 32-channel bf16 NHWC image: channel c and a zero in channel c+16
-        d_side[pix * 32 + c] = f2bf(ds);
-        d_side[pix * 32 + 16 + c] = 0;
+        const int64_t pix = ((int64_t)n * hs + i) * ws + j;
+        const float sv = side[pix * 16 + c];
+        const float ds = fw * T + dw * G;
+        d_side[pix * 32 + c] = f2bf(ds);   // padded 32-channel bf16 NHWC image: channel c ...
+        d_side[pix * 32 + 16 + c] = 0;     // ... and a zero in channel c+16
+        a += sv * T;
+        if (WITH_SIDE_OUT) {
+            b += sv * G;
+            if (c == 0) g += G;
+        }
     }
     // block reduction over lanes with equal c: xor 16, 32 inside the wave, then LDS across waves
-    float a = sv * T, b = WITH_SIDE_OUT ? sv * G : 0.f, g = (WITH_SIDE_OUT && c == 0) ? G : 0.f;
     a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
     b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
     g += __shfl_xor(g, 16, 64); g += __shfl_xor(g, 32, 64);
     __shared__ float red[4][3][16];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = tid >> 6, lane = tid & 63;
     if (lane < 16) {
         red[wave][0][lane] = a;
         red[wave][1][lane] = b;
         red[wave][2][lane] = g;
     }
     __syncthreads();
-    if (threadIdx.x < 48) {
-        const int q = threadIdx.x / 16, cc = threadIdx.x % 16;
-        slabs[(int64_t)blockIdx.x * 48 + threadIdx.x] = (red[0][q][cc] + red[1][q][cc]) + (red[2][q][cc] + red[3][q][cc]);
+    if (tid < 48) {
+        const int q = tid / 16, cc = tid % 16;
+        const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        slabs[(int64_t)blk * 48 + tid] = (red[0][q][cc] + red[1][q][cc]) + (red[2][q][cc] + red[3][q][cc]);
     }
 }
+
+template <int S>
+struct HeadBwdLaunch {
+    static int blocks(int N, int hs, int ws) {
+        return (int)(cdiv(ws, HeadTile<S>::TJ) * cdiv(hs, HeadTile<S>::TI) * N);
+    }
+    template <bool SO>
+    static size_t lds_bytes() {
+        constexpr int f = 2 << S, k = 4 << S;
+        constexpr int WR = (HeadTile<S>::TI + 1) * f, WC = (HeadTile<S>::TJ + 1) * f;
+        return sizeof(float) * (size_t)(k * k * 16 + WR * WC * (SO ? 2 : 1) + (SO ? k * k : 0));
+    }
+    template <bool SO>
+    static int run(const float *side, const float *filt, const float *filt1, const float *fw16, const float *dw16,
+                   const float *d_fused, const float *d_so, uint16_t *d_side, float *slabs, int N, int hs, int ws,
+                   int top, int left, int H, int W, hipStream_t st) {
+        const size_t lds = lds_bytes<SO>();
+        auto kern = k_head_bwd_scale<S, SO>;
+        if (lds > 64 * 1024)
+            FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        dim3 grid((unsigned)cdiv(ws, HeadTile<S>::TJ), (unsigned)cdiv(hs, HeadTile<S>::TI), (unsigned)N);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, side, filt, filt1, fw16, dw16, d_fused, d_so, d_side, slabs, hs,
+                           ws, top, left, H, W);
+        FOSVOS_LAUNCH_CHECK();
+        return FOSVOS_OK;
+    }
+};
 
 // per-block partial sums of d_fused (for d_fuse_b)
 __global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
@@ -264,7 +332,9 @@ static inline size_t head_slab_floats(int N, int H, int W, size_t off[5]) {
         h = (h + 1) / 2;
         w = (w + 1) / 2;
         off[s] = total;
-        total += (size_t)cdiv((int64_t)N * h * w * 16, 256) * 48;
+        const int nb = s == 0 ? HeadBwdLaunch<0>::blocks(N, h, w) : s == 1 ? HeadBwdLaunch<1>::blocks(N, h, w)
+                     : s == 2 ? HeadBwdLaunch<2>::blocks(N, h, w) : HeadBwdLaunch<3>::blocks(N, h, w);
+        total += (size_t)nb * 48;
     }
     off[4] = total;
     total += kBiasBlocks;
@@ -305,20 +375,28 @@ extern "C" int fosvos_head_bwd(const float *const side[4], const int hs[4], cons
     float *wsf = reinterpret_cast<float *>(workspace);
     FinishArgs fa;
     for (int s = 0; s < 4; ++s) {
-        const int64_t total = (int64_t)N * hs[s] * ws[s] * 16;
-        const int blocks = (int)cdiv(total, 256);
         fa.slabs[s] = wsf + off[s];
-        fa.n_slabs[s] = blocks;
-        if (with_so)
-            hipLaunchKernelGGL(k_head_bwd_scale<true>, dim3(blocks), dim3(256), 0, st, side[s], filt[s], filt1[s],
-                               fuse_w + 16 * s, dsn_w + 16 * s, d_fused, d_side_out[s], d_side[s], wsf + off[s], s, hs[s],
-                               ws[s], g.top[s], g.left[s], H, W, total);
-        else
-            hipLaunchKernelGGL(k_head_bwd_scale<false>, dim3(blocks), dim3(256), 0, st, side[s], filt[s],
-                               (const float *)nullptr, fuse_w + 16 * s, (const float *)nullptr, d_fused,
-                               (const float *)nullptr, d_side[s], wsf + off[s], s, hs[s], ws[s], g.top[s], g.left[s], H, W,
-                               total);
-        FOSVOS_LAUNCH_CHECK();
+        const float *f1 = with_so ? filt1[s] : nullptr;
+        const float *dw16 = with_so ? dsn_w + 16 * s : nullptr;
+        const float *dso = with_so ? d_side_out[s] : nullptr;
+        int rc = FOSVOS_OK;
+#define FOSVOS_HEAD_CASE(SS)                                                                                          \
+    case SS:                                                                                                          \
+        fa.n_slabs[s] = HeadBwdLaunch<SS>::blocks(N, hs[s], ws[s]);                                                   \
+        rc = with_so ? HeadBwdLaunch<SS>::run<true>(side[s], filt[s], f1, fuse_w + 16 * s, dw16, d_fused, dso, d_side[s], \
+                                                    wsf + off[s], N, hs[s], ws[s], g.top[s], g.left[s], H, W, st)       \
+                     : HeadBwdLaunch<SS>::run<false>(side[s], filt[s], f1, fuse_w + 16 * s, dw16, d_fused, dso,         \
+                                                     d_side[s], wsf + off[s], N, hs[s], ws[s], g.top[s], g.left[s], H, W, \
+                                                     st);                                                             \
+        break;
+        switch (s) {
+            FOSVOS_HEAD_CASE(0)
+            FOSVOS_HEAD_CASE(1)
+            FOSVOS_HEAD_CASE(2)
+            FOSVOS_HEAD_CASE(3)
+        }
+#undef FOSVOS_HEAD_CASE
+        if (rc != FOSVOS_OK) return rc;
     }
     fa.bias_partials = wsf + off[4];
     fa.n_bias = 0;

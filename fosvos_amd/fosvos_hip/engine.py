@@ -69,7 +69,7 @@ class PackedWeights:
         return packed
 
     def deconv_diag(self, name: str, w: torch.Tensor) -> torch.Tensor:
-        """[C,C,k,k] transposed-conv weight -> its diagonal [C,k,k].  The fast head kernel applies one
+        """[C,C,k,k] transposed-conv weight -> its diagonal, channel fastest: [k,k,C].  The head kernel applies one
         k x k filter per channel; the reference initialises these layers as diagonal bilinear filters and
         freezes them (src/layers/osvos_layers.py:70-81, lr 0 at src/util/network_provider.py:154-155).
         A weight with off-diagonal mass is refused loudly rather than silently mis-evaluated."""
@@ -80,13 +80,14 @@ class PackedWeights:
         wd = w.detach()
         c = wd.shape[0]
         idx = torch.arange(c, device=wd.device)
-        diag = wd[idx, idx].contiguous()
+        diag = wd[idx, idx]  # [C,k,k]
         if c > 1:
             off = wd.abs().sum() - diag.abs().sum()
             if float(off) != 0.0:
                 raise NotImplementedError(
                     f"{name}: transposed-conv weight has off-diagonal (cross-channel) entries; the HIP head "
                     f"implements the per-channel (diagonal) form the reference initialises and freezes")
+        diag = diag.permute(1, 2, 0).contiguous()  # [k,k,C]
         self._cache[name] = (key, diag)
         return diag
 

@@ -302,13 +302,13 @@ def maxpool_bwd(x: torch.Tensor, dy: torch.Tensor, relu_mask: bool = True) -> to
 def head_fwd(side: Sequence[torch.Tensor], filt: Sequence[torch.Tensor], filt1: Optional[Sequence[torch.Tensor]],
              dsn_w: Optional[torch.Tensor], dsn_b: Optional[torch.Tensor], fuse_w: torch.Tensor, fuse_b: torch.Tensor,
              H: int, W: int, with_side_out: bool = True):
-    """side[s]: fp32 NHWC [N,hs,ws,16]; filt[s]: [16,k,k]; filt1[s]: [k,k]; dsn_w [4,16]; dsn_b [4];
+    """side[s]: fp32 NHWC [N,hs,ws,16]; filt[s]: [k,k,16]; filt1[s]: [k,k]; dsn_w [4,16]; dsn_b [4];
     fuse_w [64]; fuse_b [1].  Returns (fused [N,1,H,W], [4 side outputs] or None)."""
     n = side[0].shape[0]
     for s in range(4):
         _need(side[s], _F32, "head_fwd side"); _need(filt[s], _F32, "head_fwd filt")
         k = 4 << s
-        if side[s].shape[3] != 16 or tuple(filt[s].shape) != (16, k, k):
+        if side[s].shape[3] != 16 or tuple(filt[s].shape) != (k, k, 16):
             raise ValueError("head_fwd: side/filter shape")
     _need(fuse_w, _F32, "head_fwd fuse_w"); _need(fuse_b, _F32, "head_fwd fuse_b")
     dev_t = side[0].device

@@ -133,8 +133,8 @@ int fosvos_maxpool2x2_ceil_bwd(const uint16_t *x, const uint16_t *dy, uint16_t *
  * [N,hs[s],ws[s],16]:
  *   fused[n,0,Y,X]   = fuse_b + sum_s sum_c fuse_w[16 s + c] * crop(up_s(side[s]))[c,Y,X]
  *   side_out[s][..]  = crop(up1_s(dsn_b[s] + sum_c dsn_w[s][c] * side[s][c]))        (optional)
- * up_s is the transposed conv with the DIAGONAL of upscale[s].weight, passed as filt[s] =
- * [16][k][k] fp32 (one k x k filter per channel); up1_s uses filt1[s] = [k][k].  crop is the
+ * up_s is the transposed conv with the DIAGONAL of upscale[s].weight, passed channel-fastest as
+ * filt[s] = [k][k][16] fp32 (one k x k filter per channel); up1_s uses filt1[s] = [k][k].  crop is the
  * reference's centre crop (floor(d/2) leading pixels removed).
  * replaces: upscale[s], upscale_[s], score_dsn[s], center_crop, torch.cat and fuse
  *           (src/networks/osvos_vgg.py:69-82, src/layers/osvos_layers.py:47-54). */

@@ -313,7 +313,7 @@ def test_head_fwd_bwd(ops, n, H, W):
     dev = lambda t: t.contiguous().to(DEV)
     side_d = [dev(s.permute(0, 2, 3, 1)) for s in side]
     idx = torch.arange(16)
-    filt = [dev(u[idx, idx]) for u in up]
+    filt = [dev(u[idx, idx].permute(1, 2, 0)) for u in up]  # [k,k,16], channel fastest
     filt1 = [dev(u[0, 0]) for u in up1]
     fused, so = ops.head_fwd(side_d, filt, filt1, dev(dsn_w), dev(dsn_b), dev(fuse_w), dev(fuse_b), H, W, True)
     assert rel_err(fused.cpu(), ref[4].detach()) < 1e-5
