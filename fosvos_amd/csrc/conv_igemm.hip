@@ -61,8 +61,10 @@ struct Tile {
     static_assert(BM % WM == 0 && BN % WN == 0, "wave split");
 };
 
+// waves_per_eu(2,2): two workgroups per CU, up to 256 registers each - without the cap hipcc spills the
+// prefetched chunk to scratch to reach an occupancy the LDS image would not allow anyway
 template <class T, bool OUT_F32>
-__global__ __launch_bounds__(256) void k_conv3x3_igemm(const ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv3x3_igemm(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     uint4 *sA = smem;
     uint4 *sB = smem + T::A_SLOTS;
@@ -82,22 +84,29 @@ __global__ __launch_bounds__(256) void k_conv3x3_igemm(const ConvArgs a) {
 
     // ---- A staging plan: 8 consecutive lanes = 8 consecutive pixels of one k-group (conflict-free
     // ds_write_b128), the 4 k-groups of those pixels in the next 3 octets (same 64-byte global runs)
+    // Loads are UNCONDITIONAL (addresses clamped into the image) and padding is applied as a select when the
+    // registers are written to LDS: a load under a branch makes hipcc drain vmcnt(0) inside the prefetch block.
     int a_goff[T::A_IT];
     int a_slot[T::A_IT];
+    unsigned a_ok = 0;  // bit it: the element is a real image pixel (otherwise zero padding)
 #pragma unroll
     for (int it = 0; it < T::A_IT; ++it) {
         const int idx = it * 256 + tid;
         const int oct = idx >> 5, within = idx & 31;
         const int kg = within >> 3;
         const int P = oct * 8 + (within & 7);
-        a_goff[it] = -1;
         a_slot[it] = -1;
+        int gy = y0, gx = x0;
         if (P < T::NPIX) {
             const int hy = P / T::HALO_W, hx = P - hy * T::HALO_W;
-            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            gy = y0 + hy - 1;
+            gx = x0 + hx - 1;
             a_slot[it] = kg * T::NPIX_PAD + P;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) a_goff[it] = (gy * W + gx) * Cin + kg * 8;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) a_ok |= 1u << it;
         }
+        gy = min(max(gy, 0), H - 1);
+        gx = min(max(gx, 0), W - 1);
+        a_goff[it] = (gy * W + gx) * Cin + kg * 8;
     }
 
     f32x4 acc[T::MF][T::NF];
@@ -119,28 +128,56 @@ __global__ __launch_bounds__(256) void k_conv3x3_igemm(const ConvArgs a) {
     const int n_chunks = Cin >> 5;
     const int c_begin = a.k_splits > 1 ? blockIdx.z * a.chunks_per_split : 0;
     const int c_end = a.k_splits > 1 ? min(c_begin + a.chunks_per_split, n_chunks) : n_chunks;
+
+    // Software pipeline (register prefetch, one LDS image): the global loads of chunk cc+1 are issued right
+    // before the MFMA phase of chunk cc and only waited for when they are written to LDS after it, so the
+    // L2/HBM latency hides under the matrix work (and under the co-resident workgroup's).
+    // The prefetch registers are NAMED scalars (macro-unrolled), not arrays: hipcc demoted the array form to
+    // scratch memory (store-after-load + reload), which serialises the pipeline.
+    static_assert(T::A_IT <= 6 && T::B_IT <= 9, "prefetch register file");
+    uint4 pa0, pa1, pa2, pa3, pa4, pa5, pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7, pb8;
+    pa0 = pa1 = pa2 = pa3 = pa4 = pa5 = pb0 = pb1 = pb2 = pb3 = pb4 = pb5 = pb6 = pb7 = pb8 = make_uint4(0, 0, 0, 0);
+    const uint4 *wbase = reinterpret_cast<const uint4 *>(a.w) + n0;
+#define FOSVOS_LD_A(i) \
+    if constexpr (i < T::A_IT) pa##i = *reinterpret_cast<const uint4 *>(xn + a_goff[i] + cc_ * 32);
+#define FOSVOS_LD_B(i)                                                                                  \
+    if constexpr (i < T::B_IT) {                                                                        \
+        const int idx_ = min(i * 256 + tid, T::B_SLOTS - 1);                                            \
+        pb##i = wbase[((int64_t)cc_ * 36 + idx_ / T::BN) * a.Co_pad + (idx_ % T::BN)];                   \
+    }
+#define FOSVOS_LOAD_CHUNK(cc_expr)                                                                      \
+    {                                                                                                   \
+        const int cc_ = (cc_expr);                                                                      \
+        FOSVOS_LD_A(0) FOSVOS_LD_A(1) FOSVOS_LD_A(2) FOSVOS_LD_A(3) FOSVOS_LD_A(4) FOSVOS_LD_A(5)       \
+        FOSVOS_LD_B(0) FOSVOS_LD_B(1) FOSVOS_LD_B(2) FOSVOS_LD_B(3) FOSVOS_LD_B(4) FOSVOS_LD_B(5)       \
+        FOSVOS_LD_B(6) FOSVOS_LD_B(7) FOSVOS_LD_B(8)                                                    \
+    }
+#define FOSVOS_ST_A(i)                                                                                  \
+    if constexpr (i < T::A_IT) {                                                                        \
+        if (a_slot[i] >= 0) {                                                                           \
+            const bool ok_ = (a_ok >> i) & 1u;                                                          \
+            uint4 v_ = pa##i;                                                                           \
+            v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
+            sA[a_slot[i]] = v_;                                                                         \
+        }                                                                                               \
+    }
+#define FOSVOS_ST_B(i)                                                                                  \
+    if constexpr (i < T::B_IT) {                                                                        \
+        if (i * 256 + tid < T::B_SLOTS) sB[i * 256 + tid] = pb##i;                                      \
+    }
+#define FOSVOS_STORE_CHUNK()                                                                            \
+    {                                                                                                   \
+        FOSVOS_ST_A(0) FOSVOS_ST_A(1) FOSVOS_ST_A(2) FOSVOS_ST_A(3) FOSVOS_ST_A(4) FOSVOS_ST_A(5)       \
+        FOSVOS_ST_B(0) FOSVOS_ST_B(1) FOSVOS_ST_B(2) FOSVOS_ST_B(3) FOSVOS_ST_B(4) FOSVOS_ST_B(5)       \
+        FOSVOS_ST_B(6) FOSVOS_ST_B(7) FOSVOS_ST_B(8)                                                    \
+    }
+
+    if (c_begin < c_end) FOSVOS_LOAD_CHUNK(c_begin)
     for (int cc = c_begin; cc < c_end; ++cc) {
-        if (cc > c_begin) __syncthreads();
-        // ---- stage A (input halo tile, zero outside the image)
-#pragma unroll
-        for (int it = 0; it < T::A_IT; ++it) {
-            if (a_slot[it] >= 0) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (a_goff[it] >= 0) v = *reinterpret_cast<const uint4 *>(xn + a_goff[it] + cc * 32);
-                sA[a_slot[it]] = v;
-            }
-        }
-        // ---- stage B (weights: [tap*4+kg] rows of Co_pad slots, BN of them for this block)
-        const uint4 *wsrc = reinterpret_cast<const uint4 *>(a.w) + (int64_t)cc * 36 * a.Co_pad + n0;
-#pragma unroll
-        for (int it = 0; it < T::B_IT; ++it) {
-            const int idx = it * 256 + tid;
-            if (idx < T::B_SLOTS) {
-                const int row = idx / T::BN, col = idx % T::BN;
-                sB[idx] = wsrc[(int64_t)row * a.Co_pad + col];
-            }
-        }
+        if (cc > c_begin) __syncthreads();  // every wave finished reading the previous chunk
+        FOSVOS_STORE_CHUNK()
         __syncthreads();
+        if (cc + 1 < c_end) FOSVOS_LOAD_CHUNK(cc + 1)
         // ---- 9 taps x (MF x NF) MFMAs
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
