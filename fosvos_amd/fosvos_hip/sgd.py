@@ -16,7 +16,7 @@ from . import SgdEntry, check, lib
 
 
 class FusedSGD(optim.SGD):
-    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0, weight_decay=0.0, nesterov=False, **kw):
+    def __init__(self, params, lr=1e-3, momentum=0, dampening=0, weight_decay=0, nesterov=False, **kw):
         if dampening != 0 or nesterov:
             raise NotImplementedError("FusedSGD implements the reference recipe: dampening=0, nesterov=False")
         kw.pop("foreach", None)
