@@ -105,10 +105,16 @@ def main():
                              f"(WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # one process per GPU; FOSVOS_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals on a 1-GPU box
+    backend = os.environ.get("FOSVOS_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        parallel.init_distributed("nccl")
+        if backend == "nccl":
+            parallel.init_distributed("nccl")
+        else:
+            dist.init_process_group(backend=backend)
 
     # ---- model: seeded random-init weights of the real architecture (no checkpoints offline)
     torch.manual_seed(1234)
@@ -179,11 +185,15 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
+        # rank-0-only pass: it must not issue collectives (the other ranks are already at the final barrier)
+        dp_was = train_online.data_parallel
+        train_online.data_parallel = False
         prof = ops.OpProfiler()
         ops.set_profiler(prof)
         n_prof = 5
-        run(n_prof)
+        train_online._train(prov, batch, opt, _NullWriter(), "bench", 0, n_prof, AVG_GRAD_EVERY_N, 10 ** 9)
         ops.set_profiler(None)
+        train_online.data_parallel = dp_was
         agg = prof.summary()
         by_kernel = {}
         for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
