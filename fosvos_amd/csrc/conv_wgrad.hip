@@ -45,13 +45,31 @@ __device__ __forceinline__ bf16x8 tr_pair(const char *p0, const char *p1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// 16 zero bytes every out-of-image lane of an LDS-DMA load reads instead (DMA cannot synthesise padding)
+__device__ uint4 g_zero16;
+
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+typedef const __attribute__((address_space(1))) void *glb_void_ptr;
+
+// One wave instruction: lane l moves the 16 bytes at `src` to LDS `dst_wave_base + 16 l` without touching a VGPR.
+__device__ __forceinline__ void dma16(const void *src, char *dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)dst_wave_base, 16, 0, 0);
+}
+
+// Tile pipeline: LDS-DMA (global_load_lds_dwordx4) into a DOUBLE-buffered pair of tile images, one barrier
+// per tile: while the MFMAs of tile t read image t&1, the DMA of tile t+1 lands in the other image; the
+// __syncthreads() at the end of the iteration drains it (hipcc emits vmcnt(0) in front of the barrier while a DMA
+// is in flight) and retires image t&1.  No prefetch registers, no zero-selects, no ds_write phase.
+// A DMA instruction writes 64 consecutive 16-byte slots = 32 pixel rows of one 16-channel block, which is
+// exactly how the images are laid out ([block][pixel][32 B]); lane l <-> (pixel l>>1, half l&1).  Wave w moves
+// dy pixel group w (tile rows 2w, 2w+1) for every co block and the WHOLE x halo block w - the one it consumes.
+constexpr int NPHP = (NPH + 31) / 32 * 32;  // 192: x image pixel count padded to whole DMA instructions
+
 template <int BCO>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void k_wgrad(const WgArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_wgrad(const WgArgs a) {
     constexpr int CF = BCO / 16;
-    constexpr int CF_LOG = CF == 4 ? 2 : (CF == 2 ? 1 : 0);
+    constexpr int Y_BYTES = CF * TPIX * 32, X_BYTES = 4 * NPHP * 32, BUF_BYTES = Y_BYTES + X_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem_w[];
-    char *sY = smem_w;                     // [CF][TPIX][32 B]
-    char *sX = smem_w + CF * TPIX * 32;    // [4][NPH][32 B]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,164 +86,102 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
         for (int t = 0; t < 9; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // per-lane byte offsets inside a tile image for the transposed reads
-    const int rd_y = (4 * g + q) * 32 + p * 8;               // + (cb*TPIX + row*16) * 32
-    const int rd_x = (wave * NPH + 4 * g + q) * 32 + p * 8;  // + ((row+ky)*18 + kx) * 32
+    const int rd_y = (4 * g + q) * 32 + p * 8;                          // + (cb*TPIX + row*16) * 32
+    const int rd_x = Y_BYTES + (wave * NPHP + 4 * g + q) * 32 + p * 8;  // + ((row+ky)*18 + kx) * 32
 
-    // bias gradient: the staging loop below gives every thread the SAME 8 dy channels (cb, half) for every
-    // pixel it loads, so their column sums accumulate in registers; only the ci-block-0 workgroups keep them
     const bool do_bias = a.bias_part != nullptr && blockIdx.y == 0;
     float bsum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
+    // ---- tile-independent DMA descriptors of this lane
+    const int half = lane & 1, pl = lane >> 1;  // pl: pixel inside a 32-pixel DMA group
+    // dy: pixel group = wave -> tile row 2*wave + (pl>>4), column pl&15
+    const int y_ty = 2 * wave + (pl >> 4), y_tx = pl & 15;
+    const int y_off = (y_ty * W + y_tx) * a.Cy + co0 + half * 8;  // + cb*16 per instruction
+    // x: 6 groups of 32 halo pixels of block `wave`
+    int x_off[6], x_rc[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int pix = k * 32 + pl;
+        const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+        x_rc[k] = pix < NPH ? ((hy << 16) | hx) : (0x7fff << 16);  // padding slots: never "in image"
+        x_off[k] = ((hy - 1) * W + (hx - 1)) * a.Ci + ci0 + wave * 16 + half * 8;
+    }
+    const void *zero = &g_zero16;
+
     const int t_begin = split * a.tiles_per_split;
     const int t_end = min(t_begin + a.tiles_per_split, a.n_tiles);
-
-    // ---- software pipeline: register prefetch of tile t+1 under the MFMAs of tile t, one LDS image.
-    // This kernel runs ONE wave per SIMD (144 accumulators), so every non-MFMA instruction in the tile loop
-    // is exposed.  Everything tile-independent is therefore hoisted: per staged 16-byte unit the thread keeps
-    // its global element offset relative to the tile origin, its LDS byte offset and its (row, column) inside
-    // the tile; per tile only a base pointer, two bounds and a select per unit remain.  Prefetch registers and
-    // descriptors are NAMED scalars (macro-unrolled): hipcc demotes the array form to scratch memory.
-    constexpr int Y_IT = (TPIX * CF * 2 + 255) / 256;
-    constexpr int X_IT = (NPH * 4 * 2 + 255) / 256;
-    static_assert(Y_IT <= 4 && X_IT <= 6, "prefetch register file");
-    uint4 py0, py1, py2, py3, px0, px1, px2, px3, px4, px5;
-    py0 = py1 = py2 = py3 = px0 = px1 = px2 = px3 = px4 = px5 = make_uint4(0, 0, 0, 0);
-    unsigned ok_y = 0, ok_x = 0;  // bit i: unit i of the prefetched tile is a real pixel (else zero padding)
-#define FOSVOS_WG_DESC_Y(i)                                                                                       \
-    int yoff##i = 0, ylds##i = -1, yrc##i = 0;                                                                    \
-    if constexpr (i < Y_IT) {                                                                                     \
-        const int idx_ = i * 256 + tid;                                                                           \
-        const int half_ = idx_ & 1, pl_ = (idx_ >> 1) & 3, cb_ = (idx_ >> 3) & (CF - 1), ph_ = idx_ >> (3 + CF_LOG); \
-        const int pix_ = ph_ * 4 + pl_;                                                                           \
-        if (idx_ < TPIX * CF * 2) {                                                                               \
-            yrc##i = ((pix_ >> 4) << 8) | (pix_ & 15);                                                            \
-            yoff##i = ((pix_ >> 4) * W + (pix_ & 15)) * a.Cy + co0 + cb_ * 16 + half_ * 8;                        \
-            ylds##i = (cb_ * TPIX + pix_) * 32 + half_ * 16;                                                      \
-        }                                                                                                         \
-    }
-#define FOSVOS_WG_DESC_X(i)                                                                                       \
-    int xoff##i = 0, xlds##i = -1, xrc##i = 0;                                                                    \
-    if constexpr (i < X_IT) {                                                                                     \
-        const int idx_ = i * 256 + tid;                                                                           \
-        const int half_ = idx_ & 1, pl_ = (idx_ >> 1) & 3, cb_ = (idx_ >> 3) & 3, ph_ = idx_ >> 5;                 \
-        const int pix_ = ph_ * 4 + pl_;                                                                           \
-        if (idx_ < NPH * 8) {                                                                                     \
-            const int hy_ = pix_ / HALO_W, hx_ = pix_ - hy_ * HALO_W;                                             \
-            xrc##i = (hy_ << 8) | hx_;                                                                            \
-            xoff##i = ((hy_ - 1) * W + (hx_ - 1)) * a.Ci + ci0 + cb_ * 16 + half_ * 8;                            \
-            xlds##i = (cb_ * NPH + pix_) * 32 + half_ * 16;                                                       \
-        }                                                                                                         \
-    }
-    FOSVOS_WG_DESC_Y(0) FOSVOS_WG_DESC_Y(1) FOSVOS_WG_DESC_Y(2) FOSVOS_WG_DESC_Y(3)
-    FOSVOS_WG_DESC_X(0) FOSVOS_WG_DESC_X(1) FOSVOS_WG_DESC_X(2) FOSVOS_WG_DESC_X(3) FOSVOS_WG_DESC_X(4) FOSVOS_WG_DESC_X(5)
-
-    // loads are unconditional (a load under a branch makes hipcc drain vmcnt(0) inside the prefetch block):
-    // out-of-image units read the tile's first pixel instead and are zeroed when written to LDS
-#define FOSVOS_WG_LDY(i)                                                                                          \
-    if constexpr (i < Y_IT) {                                                                                     \
-        const bool ok_ = ((yrc##i >> 8) < vrows_) && ((yrc##i & 255) < vcols_);                                   \
-        ok_y = ok_ ? (ok_y | (1u << i)) : (ok_y & ~(1u << i));                                                    \
-        py##i = *reinterpret_cast<const uint4 *>(ybase_ + (ok_ ? yoff##i : co0));                                 \
-    }
-#define FOSVOS_WG_LDX(i)                                                                                          \
-    if constexpr (i < X_IT) {                                                                                     \
-        const int hy_ = xrc##i >> 8, hx_ = xrc##i & 255;                                                          \
-        const bool ok_ = (hy_ >= ylo_) && (hy_ <= vrows_) && (hx_ >= xlo_) && (hx_ <= vcols_);                    \
-        ok_x = ok_ ? (ok_x | (1u << i)) : (ok_x & ~(1u << i));                                                    \
-        px##i = *reinterpret_cast<const uint4 *>(xbase_ + (ok_ ? xoff##i : ci0));                                 \
-    }
-    // (n, y0, x0) of the tile to load; vrows/vcols = image rows/columns left from the tile origin
-#define FOSVOS_WG_LOAD_TILE()                                                                                     \
-    {                                                                                                             \
-        const int y0_ = lt_y * TH, x0_ = lt_x * 16;                                                               \
-        const int vrows_ = H - y0_, vcols_ = W - x0_;                                                             \
-        const int ylo_ = 1 - y0_, xlo_ = 1 - x0_;                                                                 \
-        const int64_t org_ = ((int64_t)lt_n * H + y0_) * W + x0_;                                                 \
-        const uint16_t *ybase_ = a.dy + org_ * a.Cy;                                                              \
-        const uint16_t *xbase_ = a.x + org_ * a.Ci;                                                               \
-        FOSVOS_WG_LDY(0) FOSVOS_WG_LDY(1) FOSVOS_WG_LDY(2) FOSVOS_WG_LDY(3)                                       \
-        FOSVOS_WG_LDX(0) FOSVOS_WG_LDX(1) FOSVOS_WG_LDX(2) FOSVOS_WG_LDX(3) FOSVOS_WG_LDX(4) FOSVOS_WG_LDX(5)     \
-        if (++lt_x == a.tiles_x) {                                                                                \
-            lt_x = 0;                                                                                             \
-            if (++lt_y == a.tiles_y) { lt_y = 0; ++lt_n; }                                                        \
-        }                                                                                                         \
-    }
-#define FOSVOS_WG_STY(i)                                                                                          \
-    if constexpr (i < Y_IT) {                                                                                     \
-        if (ylds##i >= 0) {                                                                                       \
-            const bool ok_ = (ok_y >> i) & 1u;                                                                    \
-            uint4 v_ = py##i;                                                                                     \
-            v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u;       \
-            *reinterpret_cast<uint4 *>(sY + ylds##i) = v_;                                                        \
-            if (do_bias) {                                                                                        \
-                float f_[8];                                                                                      \
-                unpack8(v_, f_);                                                                                  \
-                _Pragma("unroll") for (int e = 0; e < 8; ++e) bsum[e] += f_[e];                                   \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-#define FOSVOS_WG_STX(i)                                                                                          \
-    if constexpr (i < X_IT) {                                                                                     \
-        if (xlds##i >= 0) {                                                                                       \
-            const bool ok_ = (ok_x >> i) & 1u;                                                                    \
-            uint4 v_ = px##i;                                                                                     \
-            v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u;       \
-            *reinterpret_cast<uint4 *>(sX + xlds##i) = v_;                                                        \
-        }                                                                                                         \
-    }
-#define FOSVOS_WG_STORE_TILE()                                                                                    \
-    {                                                                                                             \
-        FOSVOS_WG_STY(0) FOSVOS_WG_STY(1) FOSVOS_WG_STY(2) FOSVOS_WG_STY(3)                                       \
-        FOSVOS_WG_STX(0) FOSVOS_WG_STX(1) FOSVOS_WG_STX(2) FOSVOS_WG_STX(3) FOSVOS_WG_STX(4) FOSVOS_WG_STX(5)     \
-    }
-#define FOSVOS_WG_KSTEP(ks)                                                                                       \
-    {                                                                                                             \
-        bf16x8 af[CF];                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < CF; ++i) {                                                          \
-            const char *base = sY + rd_y + (i * TPIX + (ks) * 32) * 32;                                           \
-            af[i] = tr_pair(base, base + 16 * 32);                                                                \
-        }                                                                                                         \
-        _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) {                                                     \
-            const int ky = tap / 3, kx = tap % 3;                                                                 \
-            const char *base = sX + rd_x + ((2 * (ks) + ky) * HALO_W + kx) * 32;                                  \
-            const bf16x8 bfr = tr_pair(base, base + HALO_W * 32);                                                 \
-            _Pragma("unroll") for (int i = 0; i < CF; ++i)                                                        \
-                acc[i][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][tap], 0, 0, 0);          \
-        }                                                                                                         \
-    }
-
-    // tile walker: decoded once (the only divisions), then advanced incrementally by FOSVOS_WG_LOAD_TILE
     int lt_x = t_begin % a.tiles_x, lt_y = (t_begin / a.tiles_x) % a.tiles_y, lt_n = t_begin / (a.tiles_x * a.tiles_y);
-    if (t_begin < t_end) FOSVOS_WG_LOAD_TILE()
+
+    auto issue_tile = [&](char *img) {
+        const int y0 = lt_y * TH, x0 = lt_x * 16;
+        const int vrows = H - y0, vcols = W - x0;
+        const int64_t org = ((int64_t)lt_n * H + y0) * W + x0;
+        const uint16_t *ybase = a.dy + org * a.Cy;
+        const uint16_t *xbase = a.x + org * a.Ci;
+        const bool y_ok = y_ty < vrows && y_tx < vcols;
+#pragma unroll
+        for (int cb = 0; cb < CF; ++cb)
+            dma16(y_ok ? (const void *)(ybase + y_off + cb * 16) : zero, img + (cb * TPIX + wave * 32) * 32);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int hy = x_rc[k] >> 16, hx = x_rc[k] & 0xffff;
+            const bool ok = hy >= 1 - y0 && hy <= vrows && hx >= 1 - x0 && hx <= vcols;
+            dma16(ok ? (const void *)(xbase + x_off[k]) : zero, img + Y_BYTES + (wave * NPHP + k * 32) * 32);
+        }
+        if (++lt_x == a.tiles_x) {
+            lt_x = 0;
+            if (++lt_y == a.tiles_y) { lt_y = 0; ++lt_n; }
+        }
+    };
+
+    if (t_begin < t_end) issue_tile(smem_w);
+    __syncthreads();
     for (int tile = t_begin; tile < t_end; ++tile) {
-        if (tile > t_begin) __syncthreads();  // every wave finished reading the previous tile
-        FOSVOS_WG_STORE_TILE()
-        __syncthreads();
-        FOSVOS_WG_KSTEP(0)
-        // the next tile's loads go out after the first k-step so that their address arithmetic issues in the
-        // shadow of MFMAs already in flight
-        if (tile + 1 < t_end) FOSVOS_WG_LOAD_TILE()
-        FOSVOS_WG_KSTEP(1)
-        FOSVOS_WG_KSTEP(2)
-        FOSVOS_WG_KSTEP(3)
+        char *cur = smem_w + ((tile - t_begin) & 1) * BUF_BYTES;
+        if (tile + 1 < t_end) issue_tile(smem_w + (((tile - t_begin) & 1) ^ 1) * BUF_BYTES);
+        if (do_bias) {  // column sums of the dy tile: thread (cb = tid>>6, slot tid&63) keeps channels (cb, half) fixed
+            if ((tid >> 6) < CF) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float f[8];
+                    unpack8(*reinterpret_cast<const uint4 *>(cur + ((tid >> 6) * 256 + (tid & 63) + 64 * i) * 16), f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[e] += f[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < TH / 2; ++ks) {
+            bf16x8 af[CF];
+#pragma unroll
+            for (int i = 0; i < CF; ++i) {
+                const char *base = cur + rd_y + (i * TPIX + ks * 32) * 32;
+                af[i] = tr_pair(base, base + 16 * 32);
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const char *base = cur + rd_x + ((2 * ks + ky) * HALO_W + kx) * 32;
+                const bf16x8 bfr = tr_pair(base, base + HALO_W * 32);
+#pragma unroll
+                for (int i = 0; i < CF; ++i)
+                    acc[i][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][tap], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // drains the DMA of tile+1 (vmcnt(0)) and retires image `cur`
     }
-    static_assert(TH == 8, "four k-steps per tile");
     if (do_bias) {
-        // threads with equal (tid & 31 with the pixel bits masked) share channels: reduce the 256 x 8 partials in
-        // LDS in a fixed order: thread (unit u = half + 2*cb) <- all threads t with the same u
-        __syncthreads();
+        // 256 x 8 partials -> BCO channel sums in a fixed order: thread t owns channels (cb = t>>6, half = t&1)
         float *sb = reinterpret_cast<float *>(smem_w);  // [256][9] floats
 #pragma unroll
         for (int e = 0; e < 8; ++e) sb[tid * 9 + e] = bsum[e];
         __syncthreads();
         if (tid < BCO) {
-            const int cb = tid >> 4, half = (tid >> 3) & 1, e = tid & 7;
+            const int cb = tid >> 4, hf = (tid >> 3) & 1, e = tid & 7;
             float acc_b = 0.f;
-            // staging index bits: [half][pixel low 2][cb (CF_LOG bits)][pixel high]: enumerate the owners in order
-            for (int t2 = 0; t2 < 256; ++t2)
-                if ((t2 & 1) == half && ((t2 >> 3) & (CF - 1)) == cb) acc_b += sb[t2 * 9 + e];
+            for (int t2 = cb * 64 + hf; t2 < cb * 64 + 64; t2 += 2) acc_b += sb[t2 * 9 + e];
             a.bias_part[(int64_t)split * a.Cor + co0 + tid] = acc_b;
         }
     }
@@ -367,15 +323,20 @@ extern "C" int fosvos_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, float
     a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Cy = p.Cy; a.Cor = p.Cor;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles; a.tiles_per_split = p.tps;
     const dim3 grid((unsigned)p.S, (unsigned)(Ci / BCI), (unsigned)(p.Cor / p.bco));
+    // two tile images (dy + x) per workgroup; never less than the bias scratch [256][9] floats
+    auto lds_bytes = [](int cf) { return (size_t)2 * (cf * TPIX + 4 * NPHP) * 32; };
     if (p.bco == 64) {
-        const size_t lds = (size_t)(4 * TPIX + 4 * NPH) * 32;
-        hipLaunchKernelGGL(k_wgrad<64>, grid, dim3(256), lds, st, a);
+        static bool once = false;
+        if (!once) {
+            FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad<64>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(4)));
+            once = true;
+        }
+        hipLaunchKernelGGL(k_wgrad<64>, grid, dim3(256), lds_bytes(4), st, a);
     } else if (p.bco == 32) {
-        const size_t lds = (size_t)(2 * TPIX + 4 * NPH) * 32;
-        hipLaunchKernelGGL(k_wgrad<32>, grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL(k_wgrad<32>, grid, dim3(256), lds_bytes(2), st, a);
     } else {
-        const size_t lds = (size_t)(1 * TPIX + 4 * NPH) * 32;
-        hipLaunchKernelGGL(k_wgrad<16>, grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL(k_wgrad<16>, grid, dim3(256), lds_bytes(1), st, a);
     }
     FOSVOS_LAUNCH_CHECK();
     {
