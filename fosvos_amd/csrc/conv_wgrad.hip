@@ -65,19 +65,23 @@ __device__ __forceinline__ void dma16(const void *src, char *dst_wave_base) {
 // dy pixel group w (tile rows 2w, 2w+1) for every co block and the WHOLE x halo block w - the one it consumes.
 constexpr int NPHP = (NPH + 31) / 32 * 32;  // 192: x image pixel count padded to whole DMA instructions
 
-template <int BCO>
+// KSPLIT (the 16-channel-padded conv1_1 case, Ci = 16 = ONE ci fragment): the four waves share x block 0 and
+// split the tile's k-steps instead (wave w = k-step w); each wave writes its own slab (slab index split*4 + w).
+template <int BCO, bool KSPLIT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_wgrad(const WgArgs a) {
     constexpr int CF = BCO / 16;
-    constexpr int Y_BYTES = CF * TPIX * 32, X_BYTES = 4 * NPHP * 32, BUF_BYTES = Y_BYTES + X_BYTES;
+    constexpr int XB = KSPLIT ? 1 : 4;  // x channel blocks per image
+    constexpr int Y_BYTES = CF * TPIX * 32, X_BYTES = XB * NPHP * 32, BUF_BYTES = Y_BYTES + X_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem_w[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
     const int split = blockIdx.x;
-    const int ci0 = blockIdx.y * BCI;
+    const int ci0 = KSPLIT ? 0 : blockIdx.y * BCI;
     const int co0 = blockIdx.z * BCO;
     const int H = a.H, W = a.W;
+    const int xblk = KSPLIT ? 0 : wave;  // x channel block this wave consumes
 
     f32x4 acc[CF][9];
 #pragma unroll
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
     // per-lane byte offsets inside a tile image for the transposed reads
     const int rd_y = (4 * g + q) * 32 + p * 8;                          // + (cb*TPIX + row*16) * 32
-    const int rd_x = Y_BYTES + (wave * NPHP + 4 * g + q) * 32 + p * 8;  // + ((row+ky)*18 + kx) * 32
+    const int rd_x = Y_BYTES + (xblk * NPHP + 4 * g + q) * 32 + p * 8;  // + ((row+ky)*18 + kx) * 32
 
     const bool do_bias = a.bias_part != nullptr && blockIdx.y == 0;
     float bsum[8];
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const int pix = k * 32 + pl;
         const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
         x_rc[k] = pix < NPH ? ((hy << 16) | hx) : (0x7fff << 16);  // padding slots: never "in image"
-        x_off[k] = ((hy - 1) * W + (hx - 1)) * a.Ci + ci0 + wave * 16 + half * 8;
+        x_off[k] = ((hy - 1) * W + (hx - 1)) * a.Ci + ci0 + xblk * 16 + half * 8;
     }
     const void *zero = &g_zero16;
 
@@ -126,9 +130,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             dma16(y_ok ? (const void *)(ybase + y_off + cb * 16) : zero, img + (cb * TPIX + wave * 32) * 32);
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
+            if (KSPLIT && (k & 3) != wave) continue;  // one shared block: its 6 groups are dealt over the 4 waves
             const int hy = x_rc[k] >> 16, hx = x_rc[k] & 0xffff;
             const bool ok = hy >= 1 - y0 && hy <= vrows && hx >= 1 - x0 && hx <= vcols;
-            dma16(ok ? (const void *)(xbase + x_off[k]) : zero, img + Y_BYTES + (wave * NPHP + k * 32) * 32);
+            dma16(ok ? (const void *)(xbase + x_off[k]) : zero, img + Y_BYTES + (xblk * NPHP + k * 32) * 32);
         }
         if (++lt_x == a.tiles_x) {
             lt_x = 0;
@@ -154,6 +159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         }
 #pragma unroll
         for (int ks = 0; ks < TH / 2; ++ks) {
+            if (KSPLIT && ks != wave) continue;
             bf16x8 af[CF];
 #pragma unroll
             for (int i = 0; i < CF; ++i) {
@@ -190,8 +196,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     // store-issue-bound: ~20 us per launch).  Element (tap, co, ci) of a split's slab lives at
     //   (((cb * (Ci/16) + ci/16) * 9 + tap) * BCO*16) + (((co%BCO)/16 * 4 + (co%16)/4) * 16 + ci%16) * 4 + co%4
     // with cb = co / BCO; k_wgrad_final undoes the permutation.
-    float *slab = a.slabs + (int64_t)split * 9 * a.Cor * a.Ci;
-    const int wci = blockIdx.y * 4 + wave;  // global 16-wide ci fragment
+    float *slab = a.slabs + (int64_t)(KSPLIT ? split * 4 + wave : split) * 9 * a.Cor * a.Ci;
+    const int wci = KSPLIT ? 0 : blockIdx.y * 4 + wave;  // global 16-wide ci fragment
     float *blk = slab + ((int64_t)blockIdx.z * (a.Ci / 16) + wci) * 9 * (BCO * 16);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -222,10 +228,13 @@ __global__ __launch_bounds__(256) void k_wgrad_fold(const float *__restrict__ sl
 // (16-byte coalesced reads of the fragment-native layout), transpose through LDS and write 4 runs of 576
 // contiguous floats dw[(co*Ci + ci0)*9 ...] (OIHW).
 __global__ __launch_bounds__(256) void k_wgrad_final(const float *__restrict__ slabs, int S, int Co, int Cor, int Ci,
-                                                      int bco, int accumulate, float *__restrict__ dw,
+                                                      int Ci_real, int bco, int accumulate, float *__restrict__ dw,
                                                       const float *__restrict__ bias_part, int S_bias,
                                                       float *__restrict__ db) {
+    // Ci = channel count of the slabs (a multiple of 64, or 16 for the padded conv1_1 image); Ci_real = channels
+    // of dw (OIHW rows of Ci_real*9 floats)
     __shared__ float tile[4][64 * 9];
+    const int cw = Ci < 64 ? Ci : 64;  // ci columns handled by this block
     const int ci0 = blockIdx.x * 64, co4 = blockIdx.y * 4;
     if (db && blockIdx.x == 0) {  // the 4 channels' bias: S_bias per-split partials each, fixed-order tree
         __shared__ float redb[256];
@@ -244,8 +253,8 @@ __global__ __launch_bounds__(256) void k_wgrad_final(const float *__restrict__ s
     }
     const int64_t E = 9LL * Cor * Ci;
     const int cb = co4 / bco, cf = (co4 % bco) / 16, g = (co4 % 16) / 4;
-    for (int e = threadIdx.x; e < 576; e += 256) {
-        const int tap = e >> 6, cil = e & 63;
+    for (int e = threadIdx.x; e < 9 * cw; e += 256) {
+        const int tap = e / cw, cil = e - tap * cw;
         const int ci = ci0 + cil;
         const float *p = slabs + (((int64_t)cb * (Ci / 16) + ci / 16) * 9 + tap) * (bco * 16) +
                          ((cf * 4 + g) * 16 + (ci & 15)) * 4;
@@ -260,10 +269,11 @@ __global__ __launch_bounds__(256) void k_wgrad_final(const float *__restrict__ s
         tile[3][cil * 9 + tap] = a4.w;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 4 * 576; e += 256) {
-        const int r = e / 576, k = e - r * 576;
-        if (co4 + r >= Co) continue;
-        float *d = dw + ((int64_t)(co4 + r) * Ci + ci0) * 9 + k;
+    const int wr = (Ci_real - ci0 < cw ? Ci_real - ci0 : cw) * 9;  // floats of this block that exist in dw
+    for (int e = threadIdx.x; e < 4 * 9 * cw; e += 256) {
+        const int r = e / (9 * cw), k = e - r * (9 * cw);
+        if (co4 + r >= Co || k >= wr) continue;
+        float *d = dw + ((int64_t)(co4 + r) * Ci_real + ci0) * 9 + k;
         *d = accumulate ? *d + tile[r][k] : tile[r][k];
     }
 }
@@ -352,8 +362,81 @@ extern "C" int fosvos_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, float
             n_src = kFoldTo;
         }
         hipLaunchKernelGGL(k_wgrad_final, dim3((unsigned)(Ci / 64), (unsigned)(p.Cor / 4)), dim3(256), 0, st, src, n_src, Co,
-                           p.Cor, Ci, p.bco, accumulate, dw, (const float *)a.bias_part, p.S, db);
+                           p.Cor, Ci, Ci, p.bco, accumulate, dw, (const float *)a.bias_part, p.S, db);
         FOSVOS_LAUNCH_CHECK();
     }
+    return FOSVOS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- conv1_1
+// dw[Co,3,3,3], db[Co] of the first layer on the same MFMA kernel: the fp32 NCHW frame is first written as a
+// 16-channel zero-padded bf16 NHWC image (13 MB per 480x854 frame; the other wgrads read bf16 activations too),
+// then k_wgrad<64, KSPLIT> runs with Ci = 16 and the final pass keeps channels 0..2.
+namespace {
+struct FirstPlan {
+    int tiles_x, tiles_y, n_tiles, tps, S;
+    size_t frame_bytes, slab_bytes, bias_bytes;
+};
+FirstPlan make_first_plan(int N, int H, int W, int Co) {
+    FirstPlan p;
+    p.tiles_x = (int)cdiv(W, 16);
+    p.tiles_y = (int)cdiv(H, TH);
+    p.n_tiles = p.tiles_x * p.tiles_y * N;
+    int S = kTargetBlocks / (Co / 64);
+    if (S > p.n_tiles) S = p.n_tiles;
+    if (S < 1) S = 1;
+    p.tps = (int)cdiv(p.n_tiles, S);
+    p.S = (int)cdiv(p.n_tiles, p.tps);
+    p.frame_bytes = ((size_t)N * H * W * 16 * sizeof(uint16_t) + 255) / 256 * 256;
+    p.slab_bytes = (size_t)(4 * p.S + kFoldTo) * 9 * Co * 16 * sizeof(float);
+    p.bias_bytes = (size_t)p.S * Co * sizeof(float);
+    return p;
+}
+}  // namespace
+
+extern "C" size_t fosvos_conv3x3_first_wgrad_workspace_bytes(int N, int H, int W, int Co) {
+    if (N <= 0 || H <= 0 || W <= 0 || Co <= 0 || Co % 64 != 0) return 0;
+    const FirstPlan p = make_first_plan(N, H, W, Co);
+    return p.frame_bytes + p.slab_bytes + p.bias_bytes;
+}
+
+extern "C" int fosvos_conv3x3_first_wgrad(const float *frame, const uint16_t *dy, float *dw, float *db, int N, int H,
+                                          int W, int Co, void *workspace, size_t workspace_bytes, int device,
+                                          void *stream) {
+    FOSVOS_REQUIRE(frame && dy && dw && workspace, FOSVOS_E_ARG, "conv3x3_first_wgrad: null pointer");
+    FOSVOS_REQUIRE(Co % 64 == 0, FOSVOS_E_SHAPE, "conv3x3_first_wgrad: Co=%d must be a multiple of 64", Co);
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0, FOSVOS_E_SHAPE, "conv3x3_first_wgrad: bad shape N=%d H=%d W=%d", N, H, W);
+    const FirstPlan p = make_first_plan(N, H, W, Co);
+    const size_t need = p.frame_bytes + p.slab_bytes + p.bias_bytes;
+    FOSVOS_REQUIRE(workspace_bytes >= need, FOSVOS_E_WORKSPACE, "conv3x3_first_wgrad: workspace %zu < %zu",
+                   workspace_bytes, need);
+    char *ws = reinterpret_cast<char *>(workspace);
+    uint16_t *frame16 = reinterpret_cast<uint16_t *>(ws);
+    if (int rc = fosvos_nchw_f32_to_nhwc_bf16(frame, frame16, N, 3, H, W, 16, device, stream)) return rc;
+    FOSVOS_ENTER(device);
+    hipStream_t st = (hipStream_t)stream;
+    WgArgs a;
+    a.x = frame16; a.dy = dy; a.slabs = reinterpret_cast<float *>(ws + p.frame_bytes);
+    a.bias_part = db ? reinterpret_cast<float *>(ws + p.frame_bytes + p.slab_bytes) : nullptr;
+    a.N = N; a.H = H; a.W = W; a.Ci = 16; a.Cy = Co; a.Cor = Co;
+    a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles; a.tiles_per_split = p.tps;
+    const size_t lds = (size_t)2 * (4 * TPIX + 1 * NPHP) * 32;
+    hipLaunchKernelGGL((k_wgrad<64, true>), dim3((unsigned)p.S, 1, (unsigned)(Co / 64)), dim3(256), lds, st, a);
+    FOSVOS_LAUNCH_CHECK();
+    const int64_t E = 9LL * Co * 16;
+    const int n_slabs = 4 * p.S;
+    const float *src = a.slabs;
+    int n_src = n_slabs;
+    if (n_slabs > kFoldTo) {
+        float *folded = a.slabs + (int64_t)n_slabs * E;
+        hipLaunchKernelGGL(k_wgrad_fold, dim3((unsigned)cdiv(E / 4, 256), kFoldTo), dim3(256), 0, st, a.slabs, n_slabs, E,
+                           folded);
+        FOSVOS_LAUNCH_CHECK();
+        src = folded;
+        n_src = kFoldTo;
+    }
+    hipLaunchKernelGGL(k_wgrad_final, dim3(1, (unsigned)(Co / 4)), dim3(256), 0, st, src, n_src, Co, Co, 16, 3, 64, 0, dw,
+                       (const float *)a.bias_part, p.S, db);
+    FOSVOS_LAUNCH_CHECK();
     return FOSVOS_OK;
 }
