@@ -188,11 +188,15 @@ def main():
         # rank-0-only pass: it must not issue collectives (the other ranks are already at the final barrier)
         dp_was = train_online.data_parallel
         train_online.data_parallel = False
+        from fosvos_hip import engine
+        native_was = engine.USE_NATIVE_LOOP
+        engine.USE_NATIVE_LOOP = False  # same kernels, issued op by op from Python so that each op can be bracketed
         prof = ops.OpProfiler()
         ops.set_profiler(prof)
         n_prof = 5
         train_online._train(prov, batch, opt, _NullWriter(), "bench", 0, n_prof, AVG_GRAD_EVERY_N, 10 ** 9)
         ops.set_profiler(None)
+        engine.USE_NATIVE_LOOP = native_was
         train_online.data_parallel = dp_was
         agg = prof.summary()
         by_kernel = {}

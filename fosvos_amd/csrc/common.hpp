@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <algorithm>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -38,6 +39,15 @@ inline int fail(int code, const char *fmt, ...) {
 // Select the device for this call (backward runs on an autograd thread with its own current device).
 #define FOSVOS_ENTER(device) FOSVOS_HIP_CHECK(hipSetDevice(device))
 #define FOSVOS_LAUNCH_CHECK() FOSVOS_HIP_CHECK(hipGetLastError())
+
+// internal variants of two exported entry points with an accumulate-into-output flag (used by vgg_net.hip)
+int first_wgrad_impl(const float *frame, const uint16_t *dy, float *dw, float *db, int N, int H, int W, int Co,
+                     int accumulate, void *workspace, size_t workspace_bytes, int device, void *stream);
+int head_bwd_impl(const float *const side[4], const int hs[4], const int ws[4], const float *const filt[4],
+                  const float *const filt1[4], const float *dsn_w, const float *fuse_w, const float *d_fused,
+                  const float *const d_side_out[4], uint16_t *const d_side[4], float *d_fuse_w, float *d_fuse_b,
+                  float *d_dsn_w, float *d_dsn_b, int N, int H, int W, int accumulate, void *workspace,
+                  size_t workspace_bytes, int device, void *stream);
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int roundup(int a, int b) { return (a + b - 1) / b * b; }

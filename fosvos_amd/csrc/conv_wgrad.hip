@@ -403,6 +403,11 @@ extern "C" size_t fosvos_conv3x3_first_wgrad_workspace_bytes(int N, int H, int W
 extern "C" int fosvos_conv3x3_first_wgrad(const float *frame, const uint16_t *dy, float *dw, float *db, int N, int H,
                                           int W, int Co, void *workspace, size_t workspace_bytes, int device,
                                           void *stream) {
+    return fosvos::first_wgrad_impl(frame, dy, dw, db, N, H, W, Co, 0, workspace, workspace_bytes, device, stream);
+}
+
+int fosvos::first_wgrad_impl(const float *frame, const uint16_t *dy, float *dw, float *db, int N, int H, int W, int Co,
+                             int accumulate, void *workspace, size_t workspace_bytes, int device, void *stream) {
     FOSVOS_REQUIRE(frame && dy && dw && workspace, FOSVOS_E_ARG, "conv3x3_first_wgrad: null pointer");
     FOSVOS_REQUIRE(Co % 64 == 0, FOSVOS_E_SHAPE, "conv3x3_first_wgrad: Co=%d must be a multiple of 64", Co);
     FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0, FOSVOS_E_SHAPE, "conv3x3_first_wgrad: bad shape N=%d H=%d W=%d", N, H, W);
@@ -435,8 +440,8 @@ extern "C" int fosvos_conv3x3_first_wgrad(const float *frame, const uint16_t *dy
         src = folded;
         n_src = kFoldTo;
     }
-    hipLaunchKernelGGL(k_wgrad_final, dim3(1, (unsigned)(Co / 4)), dim3(256), 0, st, src, n_src, Co, Co, 16, 3, 64, 0, dw,
-                       (const float *)a.bias_part, p.S, db);
+    hipLaunchKernelGGL(k_wgrad_final, dim3(1, (unsigned)(Co / 4)), dim3(256), 0, st, src, n_src, Co, Co, 16, 3, 64, accumulate,
+                       dw, (const float *)a.bias_part, p.S, db);
     FOSVOS_LAUNCH_CHECK();
     return FOSVOS_OK;
 }

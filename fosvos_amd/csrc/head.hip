@@ -249,6 +249,7 @@ struct FinishArgs {
     int n_slabs[4];
     const float *bias_partials;
     int n_bias;
+    int accumulate;  // add into d_* instead of overwriting
 };
 
 // One block per scale (+ one for the bias): 16 row groups x 48 columns; group g sums slabs g, g+16, ...
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(768) void k_head_finish(FinishArgs fa, float *__res
         if (threadIdx.x == 0) {
             double t = 0.0;
             for (int w = 0; w < 12; ++w) t += red[0][w];
-            d_fuse_b[0] = (float)t;
+            d_fuse_b[0] = fa.accumulate ? d_fuse_b[0] + (float)t : (float)t;
         }
         return;
     }
@@ -280,9 +281,10 @@ __global__ __launch_bounds__(768) void k_head_finish(FinishArgs fa, float *__res
     double t = 0.0;
     for (int k = 0; k < 16; ++k) t += red[k][col];
     const int q = col / 16, c = col % 16;
-    if (q == 0) d_fuse_w[16 * s + c] = (float)t;
-    if (q == 1 && d_dsn_w) d_dsn_w[16 * s + c] = (float)t;
-    if (q == 2 && d_dsn_b && c == 0) d_dsn_b[s] = (float)t;
+    const float tf = (float)t;
+    if (q == 0) d_fuse_w[16 * s + c] = fa.accumulate ? d_fuse_w[16 * s + c] + tf : tf;
+    if (q == 1 && d_dsn_w) d_dsn_w[16 * s + c] = fa.accumulate ? d_dsn_w[16 * s + c] + tf : tf;
+    if (q == 2 && d_dsn_b && c == 0) d_dsn_b[s] = fa.accumulate ? d_dsn_b[s] + tf : tf;
 }
 
 constexpr int kBiasBlocks = 512;
@@ -352,6 +354,15 @@ extern "C" int fosvos_head_bwd(const float *const side[4], const int hs[4], cons
                                uint16_t *const d_side[4], float *d_fuse_w, float *d_fuse_b, float *d_dsn_w,
                                float *d_dsn_b, int N, int H, int W, void *workspace, size_t workspace_bytes, int device,
                                void *stream) {
+    return fosvos::head_bwd_impl(side, hs, ws, filt, filt1, dsn_w, fuse_w, d_fused, d_side_out, d_side, d_fuse_w, d_fuse_b,
+                                 d_dsn_w, d_dsn_b, N, H, W, 0, workspace, workspace_bytes, device, stream);
+}
+
+int fosvos::head_bwd_impl(const float *const side[4], const int hs[4], const int ws[4], const float *const filt[4],
+                          const float *const filt1[4], const float *dsn_w, const float *fuse_w, const float *d_fused,
+                          const float *const d_side_out[4], uint16_t *const d_side[4], float *d_fuse_w, float *d_fuse_b,
+                          float *d_dsn_w, float *d_dsn_b, int N, int H, int W, int accumulate, void *workspace,
+                          size_t workspace_bytes, int device, void *stream) {
     FOSVOS_REQUIRE(side && hs && ws && filt && fuse_w && d_side && d_fuse_w && d_fuse_b && workspace, FOSVOS_E_ARG,
                    "head_bwd: null pointer");
     FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0, FOSVOS_E_SHAPE, "head_bwd: bad shape N=%d H=%d W=%d", N, H, W);
@@ -400,6 +411,7 @@ extern "C" int fosvos_head_bwd(const float *const side[4], const int hs[4], cons
     }
     fa.bias_partials = wsf + off[4];
     fa.n_bias = 0;
+    fa.accumulate = accumulate;
     if (d_fused) {
         fa.n_bias = kBiasBlocks;
         hipLaunchKernelGGL(k_sum_partials, dim3(kBiasBlocks), dim3(256), 0, st, d_fused, (int64_t)N * H * W,

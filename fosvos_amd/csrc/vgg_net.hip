@@ -1,0 +1,197 @@
+// Native layer loop of OSVOS-VGG: one C-ABI call issues every kernel of the forward pass, one call every
+// kernel of the backward pass (reference: OSVOS_VGG.forward, src/networks/osvos_vgg.py:61-83, and the autograd
+// graph torch builds from it).  Host-side only: this file launches the kernels of the other translation units
+// through their exported entry points, over an arena whose layout is computed here.
+//
+// Why native: driven from Python, each of the ~100 ops of a training step costs ~19 us of interpreter, ctypes
+// marshalling and allocator time (1.8 ms/step - as much as the GPU needs); from C++ a launch costs ~3 us.
+#include "common.hpp"
+
+using namespace fosvos;
+
+namespace {
+constexpr int kNConv = 13;
+constexpr int kStageOf[kNConv] = {0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4};
+constexpr int kCin[kNConv] = {3, 64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512};
+constexpr int kCout[kNConv] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+constexpr int kFirstOfStage[5] = {0, 2, 4, 7, 10};
+constexpr int kLastOfStage[5] = {1, 3, 6, 9, 12};
+constexpr int kStageCh[5] = {64, 128, 256, 512, 512};
+
+inline size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct Arena {
+    int sh[5], sw[5];        // stage resolutions
+    size_t act[kNConv];      // conv outputs, bf16 NHWC
+    size_t gact[kNConv];     // gradients wrt conv outputs (ReLU-masked), bf16 NHWC
+    size_t pooled[4];        // pool outputs = inputs of stages 1..4
+    size_t gpooled[4];       // gradients wrt them
+    size_t side[4];          // fp32 NHWC [N,h,w,16]
+    size_t dside[4];         // bf16 NHWC [N,h,w,32]
+    size_t ws, ws_bytes;     // shared op workspace
+    size_t total;
+};
+
+Arena make_arena(int N, int H, int W) {
+    Arena a{};
+    a.sh[0] = H; a.sw[0] = W;
+    for (int s = 1; s < 5; ++s) { a.sh[s] = (a.sh[s - 1] + 1) / 2; a.sw[s] = (a.sw[s - 1] + 1) / 2; }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += up256(bytes); return o; };
+    for (int c = 0; c < kNConv; ++c) {
+        const int s = kStageOf[c];
+        const size_t bytes = (size_t)N * a.sh[s] * a.sw[s] * kCout[c] * 2;
+        a.act[c] = take(bytes);
+        a.gact[c] = take(bytes);
+    }
+    for (int s = 1; s < 5; ++s) {
+        const size_t bytes = (size_t)N * a.sh[s] * a.sw[s] * kStageCh[s - 1] * 2;
+        a.pooled[s - 1] = take(bytes);
+        a.gpooled[s - 1] = take(bytes);
+        a.side[s - 1] = take((size_t)N * a.sh[s] * a.sw[s] * 16 * 4);
+        a.dside[s - 1] = take((size_t)N * a.sh[s] * a.sw[s] * 32 * 2);
+    }
+    size_t ws = fosvos_conv3x3_first_wgrad_workspace_bytes(N, H, W, 64);
+    ws = std::max(ws, fosvos_head_bwd_workspace_bytes(N, H, W));
+    for (int c = 1; c < kNConv; ++c) {
+        const int s = kStageOf[c];
+        ws = std::max(ws, fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kCin[c], kCout[c]));
+        ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kCin[c], kCout[c]));   // fwd split-K
+        ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kCout[c], kCin[c]));   // dgrad split-K
+    }
+    for (int s = 1; s < 5; ++s) {
+        ws = std::max(ws, fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16));
+        ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16));
+        ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], 16, kStageCh[s]));
+    }
+    a.ws_bytes = up256(ws);
+    a.ws = take(a.ws_bytes);
+    a.total = off;
+    return a;
+}
+
+#define FOSVOS_TRY(expr)          \
+    do {                          \
+        const int rc_ = (expr);   \
+        if (rc_ != FOSVOS_OK) return rc_; \
+    } while (0)
+
+int check_net(const void *w, const void *frame, const void *arena, int N, int H, int W, size_t arena_bytes,
+              const Arena &a, const char *who) {
+    FOSVOS_REQUIRE(w && frame && arena, FOSVOS_E_ARG, "%s: null pointer", who);
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0, FOSVOS_E_SHAPE, "%s: bad shape N=%d H=%d W=%d", who, N, H, W);
+    FOSVOS_REQUIRE(arena_bytes >= a.total, FOSVOS_E_WORKSPACE, "%s: arena %zu < %zu bytes", who, arena_bytes, a.total);
+    FOSVOS_REQUIRE(((uintptr_t)arena & 255) == 0, FOSVOS_E_ARG, "%s: arena must be 256-byte aligned", who);
+    return FOSVOS_OK;
+}
+}  // namespace
+
+extern "C" size_t fosvos_vgg_arena_bytes(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    return make_arena(N, H, W).total;
+}
+
+extern "C" int fosvos_vgg_forward(const fosvos_vgg_weights *w, const float *frame, int N, int H, int W, void *arena,
+                                  size_t arena_bytes, float *fused, float *const side_out[4], int device,
+                                  void *stream) {
+    const Arena a = make_arena(N, H, W);
+    FOSVOS_TRY(check_net(w, frame, arena, N, H, W, arena_bytes, a, "vgg_forward"));
+    FOSVOS_REQUIRE(fused, FOSVOS_E_ARG, "vgg_forward: null output");
+    char *base = reinterpret_cast<char *>(arena);
+    auto act = [&](int c) { return reinterpret_cast<uint16_t *>(base + a.act[c]); };
+    void *ws = base + a.ws;
+    const uint16_t *x = nullptr;
+    for (int c = 0; c < kNConv; ++c) {
+        const int s = kStageOf[c];
+        if (c == 0) {
+            FOSVOS_TRY(fosvos_conv3x3_first_fwd(frame, w->conv_w[0], w->conv_b[0], act(0), N, H, W, kCout[0], device, stream));
+        } else {
+            if (c == kFirstOfStage[s]) {  // stage entry: 2x2 ceil max pool of the previous stage's output
+                uint16_t *p = reinterpret_cast<uint16_t *>(base + a.pooled[s - 1]);
+                FOSVOS_TRY(fosvos_maxpool2x2_ceil_fwd(x, p, N, a.sh[s - 1], a.sw[s - 1], kStageCh[s - 1], device, stream));
+                x = p;
+            }
+            FOSVOS_TRY(fosvos_conv3x3_fwd(x, w->conv_wf[c], w->conv_b[c], act(c), N, a.sh[s], a.sw[s], kCin[c], kCout[c],
+                                          FOSVOS_CONV_RELU, ws, a.ws_bytes, device, stream));
+        }
+        x = act(c);
+        if (s > 0 && c == kLastOfStage[s])
+            FOSVOS_TRY(fosvos_conv3x3_fwd(x, w->side_wf[s - 1], w->side_b[s - 1], base + a.side[s - 1], N, a.sh[s], a.sw[s],
+                                          kStageCh[s], 16, FOSVOS_CONV_OUT_F32, ws, a.ws_bytes, device, stream));
+    }
+    const float *side[4];
+    int hs[4], wsz[4];
+    for (int i = 0; i < 4; ++i) {
+        side[i] = reinterpret_cast<const float *>(base + a.side[i]);
+        hs[i] = a.sh[i + 1];
+        wsz[i] = a.sw[i + 1];
+    }
+    return fosvos_head_fwd(side, hs, wsz, w->filt, w->filt1, w->dsn_w, w->dsn_b, w->fuse_w, w->fuse_b, fused, side_out, N, H,
+                           W, device, stream);
+}
+
+extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg_grads *g, const float *frame, int N,
+                                   int H, int W, void *arena, size_t arena_bytes, const float *d_fused,
+                                   const float *const d_side_out[4], int device, void *stream) {
+    const Arena a = make_arena(N, H, W);
+    FOSVOS_TRY(check_net(w, frame, arena, N, H, W, arena_bytes, a, "vgg_backward"));
+    FOSVOS_REQUIRE(g, FOSVOS_E_ARG, "vgg_backward: null gradient table");
+    const bool with_so = d_side_out && d_side_out[0];
+    FOSVOS_REQUIRE(d_fused || with_so, FOSVOS_E_ARG, "vgg_backward: no upstream gradient given");
+    char *base = reinterpret_cast<char *>(arena);
+    auto act = [&](int c) { return reinterpret_cast<uint16_t *>(base + a.act[c]); };
+    auto gact = [&](int c) { return reinterpret_cast<uint16_t *>(base + a.gact[c]); };
+    void *ws = base + a.ws;
+    const int acc = g->accumulate ? 1 : 0;
+
+    // ---- head: d_side[i], fuse / score_dsn gradients
+    const float *side[4];
+    uint16_t *dside[4];
+    int hs[4], wsz[4];
+    for (int i = 0; i < 4; ++i) {
+        side[i] = reinterpret_cast<const float *>(base + a.side[i]);
+        dside[i] = reinterpret_cast<uint16_t *>(base + a.dside[i]);
+        hs[i] = a.sh[i + 1];
+        wsz[i] = a.sw[i + 1];
+    }
+    FOSVOS_TRY(head_bwd_impl(side, hs, wsz, w->filt, with_so ? w->filt1 : nullptr, with_so ? w->dsn_w : nullptr, w->fuse_w,
+                             d_fused, with_so ? d_side_out : nullptr, dside, g->fuse_w, g->fuse_b,
+                             with_so ? g->dsn_w : nullptr, with_so ? g->dsn_b : nullptr, N, H, W, acc, ws, a.ws_bytes, device,
+                             stream));
+
+    // ---- stages 4..0
+    for (int s = 4; s >= 0; --s) {
+        const int hh = a.sh[s], ww = a.sw[s], last = kLastOfStage[s], first = kFirstOfStage[s];
+        if (s > 0) {
+            // side_prep[s-1]: wgrad from (stage output, d_side), then its dgrad into the stage-output gradient:
+            // ReLU-masked and added to what already came back through the next stage's pool (already in gact[last])
+            FOSVOS_TRY(fosvos_conv3x3_wgrad(act(last), dside[s - 1], g->side_w[s - 1], g->side_b[s - 1], N, hh, ww,
+                                            kStageCh[s], 16, acc, ws, a.ws_bytes, device, stream));
+            const uint16_t *addend = (s < 4) ? gact(last) : nullptr;
+            FOSVOS_TRY(fosvos_conv3x3_dgrad(dside[s - 1], w->side_wd[s - 1], act(last), addend, gact(last), N, hh, ww,
+                                            kStageCh[s], 16, ws, a.ws_bytes, device, stream));
+        }
+        for (int c = last; c >= first; --c) {
+            if (c == 0) {
+                FOSVOS_TRY(first_wgrad_impl(frame, gact(0), g->conv_w[0], g->conv_b[0], N, H, W, kCout[0], acc, ws,
+                                            a.ws_bytes, device, stream));
+                break;
+            }
+            const bool from_pool = (c == first);  // its input is the pool output (s >= 1) - conv 1 reads conv 0
+            const uint16_t *xin = from_pool && s > 0 ? reinterpret_cast<const uint16_t *>(base + a.pooled[s - 1]) : act(c - 1);
+            FOSVOS_TRY(fosvos_conv3x3_wgrad(xin, gact(c), g->conv_w[c], g->conv_b[c], N, hh, ww, kCin[c], kCout[c], acc, ws,
+                                            a.ws_bytes, device, stream));
+            // dgrad: into the previous conv's output gradient (masked by its ReLU), or into the pool-output gradient
+            // (unmasked: the pool backward applies the producer's mask)
+            uint16_t *dx = from_pool && s > 0 ? reinterpret_cast<uint16_t *>(base + a.gpooled[s - 1]) : gact(c - 1);
+            const uint16_t *mask = from_pool && s > 0 ? nullptr : act(c - 1);
+            FOSVOS_TRY(fosvos_conv3x3_dgrad(gact(c), w->conv_wd[c], mask, nullptr, dx, N, hh, ww, kCin[c], kCout[c], ws,
+                                            a.ws_bytes, device, stream));
+        }
+        if (s > 0)  // pool backward into the previous stage's output gradient, its ReLU mask fused
+            FOSVOS_TRY(fosvos_maxpool2x2_ceil_bwd(act(kLastOfStage[s - 1]), reinterpret_cast<const uint16_t *>(base + a.gpooled[s - 1]),
+                                                  gact(kLastOfStage[s - 1]), N, a.sh[s - 1], a.sw[s - 1], kStageCh[s - 1], 1,
+                                                  device, stream));
+    }
+    return FOSVOS_OK;
+}

@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 CONV_RELU = 1
 CONV_OUT_F32 = 2
 
@@ -31,6 +31,21 @@ class SgdEntry(ctypes.Structure):
 
 _P4 = c_void_p * 4
 _I4 = c_int * 4
+_P13 = c_void_p * 13
+
+
+class VggWeights(ctypes.Structure):
+    """fosvos_vgg_weights (include/fosvos_hip.h): device pointers, struct itself in host memory."""
+    _fields_ = [("conv_w", _P13), ("conv_b", _P13), ("conv_wf", _P13), ("conv_wd", _P13),
+                ("side_b", _P4), ("side_wf", _P4), ("side_wd", _P4), ("filt", _P4), ("filt1", _P4),
+                ("dsn_w", c_void_p), ("dsn_b", c_void_p), ("fuse_w", c_void_p), ("fuse_b", c_void_p)]
+
+
+class VggGrads(ctypes.Structure):
+    """fosvos_vgg_grads."""
+    _fields_ = [("conv_w", _P13), ("conv_b", _P13), ("side_w", _P4), ("side_b", _P4),
+                ("dsn_w", c_void_p), ("dsn_b", c_void_p), ("fuse_w", c_void_p), ("fuse_b", c_void_p),
+                ("accumulate", c_int)]
 
 # name -> (restype, argtypes); every entry point of include/fosvos_hip.h
 SIGNATURES = {
@@ -71,6 +86,11 @@ SIGNATURES = {
                                  c_int, c_void_p]),
     "fosvos_cbce_workspace_bytes": (c_size_t, [c_int64]),
     "fosvos_sgd_momentum_step": (c_int, [c_void_p, c_int, c_int64, c_float, c_int, c_int, c_void_p]),
+    "fosvos_vgg_arena_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "fosvos_vgg_forward": (c_int, [POINTER(VggWeights), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
+                                   POINTER(c_void_p), c_int, c_void_p]),
+    "fosvos_vgg_backward": (c_int, [POINTER(VggWeights), POINTER(VggGrads), c_void_p, c_int, c_int, c_int, c_void_p,
+                                    c_size_t, c_void_p, POINTER(c_void_p), c_int, c_void_p]),
 }
 
 _lib = None

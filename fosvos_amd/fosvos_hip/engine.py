@@ -54,10 +54,21 @@ class PackedWeights:
 
     def __init__(self) -> None:
         self._cache: Dict[str, Tuple[Tuple[int, int], object]] = {}
+        self.arenas = ArenaPool()
 
     @staticmethod
     def _key(t: torch.Tensor) -> Tuple[int, int]:
         return (t.data_ptr(), t._version)
+
+    def small(self, name: str, parts: Sequence[torch.Tensor]) -> torch.Tensor:
+        """Concatenation of a few tiny parameters (the four score_dsn layers) as one contiguous vector."""
+        key = tuple(self._key(t) for t in parts)
+        hit = self._cache.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        cat = torch.cat([t.detach().reshape(-1) for t in parts]).contiguous()
+        self._cache[name] = (key, cat)
+        return cat
 
     def conv(self, name: str, w: torch.Tensor):
         key = self._key(w)
@@ -247,6 +258,171 @@ def backward(P: Dict[str, torch.Tensor], packs: PackedWeights, sv: "Saved", d_ou
     return grads
 
 
+# ------------------------------------------------------------------------------------------------------
+# Native layer loop (csrc/vgg_net.hip): one C-ABI call per forward, one per backward
+# ------------------------------------------------------------------------------------------------------
+import ctypes  # noqa: E402
+import os  # noqa: E402
+
+from . import VggGrads, VggWeights, check, lib, ptr_array4  # noqa: E402
+
+USE_NATIVE_LOOP = os.environ.get("FOSVOS_PY_ENGINE", "0") != "1"  # debugging switch: Python-driven per-op loop
+
+_CONV_NAMES = [(wn, bn) for (_, _, _, _, wn, bn) in CONVS]
+
+
+class ArenaPool:
+    """Activation/gradient/workspace arenas, one size per (N, H, W); the library never allocates."""
+
+    def __init__(self) -> None:
+        self._free: Dict[Tuple[int, int, int, int], List[torch.Tensor]] = {}
+
+    def take(self, n: int, h: int, w: int, device: torch.device) -> torch.Tensor:
+        key = (n, h, w, device.index if device.index is not None else torch.cuda.current_device())
+        free = self._free.setdefault(key, [])
+        if free:
+            return free.pop()
+        nbytes = lib().fosvos_vgg_arena_bytes(n, h, w)
+        return torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+
+    def give(self, n: int, h: int, w: int, arena: torch.Tensor) -> None:
+        key = (n, h, w, arena.device.index)
+        free = self._free.setdefault(key, [])
+        if len(free) < 2:
+            free.append(arena)
+
+
+def _aligned_ptr(arena: torch.Tensor) -> Tuple[int, int]:
+    p = arena.data_ptr()
+    ap = (p + 255) // 256 * 256
+    return ap, arena.numel() - (ap - p)
+
+
+def _weights_struct(P: Dict[str, torch.Tensor], packs: PackedWeights):
+    """fosvos_vgg_weights for the current parameter values + the tensors it points into (kept alive by the caller)."""
+    w = VggWeights()
+    keep = []
+    for c, (wn, bn) in enumerate(_CONV_NAMES):
+        w.conv_w[c] = P[wn].data_ptr()
+        w.conv_b[c] = P[bn].data_ptr()
+        if c > 0:
+            wf, wd = packs.conv(wn, P[wn])
+            w.conv_wf[c], w.conv_wd[c] = wf.data_ptr(), wd.data_ptr()
+    for i in range(4):
+        wf, wd = packs.conv(f"side_prep.{i}.weight", P[f"side_prep.{i}.weight"])
+        w.side_wf[i], w.side_wd[i] = wf.data_ptr(), wd.data_ptr()
+        w.side_b[i] = P[f"side_prep.{i}.bias"].data_ptr()
+        f = packs.deconv_diag(f"upscale.{i}.weight", P[f"upscale.{i}.weight"])
+        f1 = packs.deconv_diag(f"upscale_.{i}.weight", P[f"upscale_.{i}.weight"])
+        w.filt[i], w.filt1[i] = f.data_ptr(), f1.data_ptr()
+    dsn_w = packs.small("dsn_w", [P[f"score_dsn.{i}.weight"] for i in range(4)])
+    dsn_b = packs.small("dsn_b", [P[f"score_dsn.{i}.bias"] for i in range(4)])
+    w.dsn_w, w.dsn_b = dsn_w.data_ptr(), dsn_b.data_ptr()
+    w.fuse_w, w.fuse_b = P["fuse.weight"].data_ptr(), P["fuse.bias"].data_ptr()
+    keep += [dsn_w, dsn_b]
+    return w, keep
+
+
+def native_forward(P, packs, pool: ArenaPool, x: torch.Tensor, with_side_out: bool, keep: bool):
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError(f"OSVOS_VGG expects [N,3,H,W] frames, got {tuple(x.shape)}")
+    if not x.is_cuda:
+        raise RuntimeError("the HIP OSVOS_VGG runs on the GPU only: move the module and the frame to cuda "
+                           "(there is no CPU fallback)")
+    for name in ("stages.0.0.weight", "fuse.weight"):
+        if not P[name].is_cuda or P[name].dtype != torch.float32:
+            raise RuntimeError("OSVOS_VGG parameters must be fp32 tensors on the GPU")
+    x = x.contiguous().float()
+    N, _, H, W = x.shape
+    dev = x.device
+    arena = pool.take(N, H, W, dev)
+    ap, an = _aligned_ptr(arena)
+    w, keep_alive = _weights_struct(P, packs)
+    fused = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
+    outs = [torch.empty((N, 1, H, W), dtype=torch.float32, device=dev) for _ in range(4)] if with_side_out else None
+    so = ptr_array4([o.data_ptr() for o in outs]) if with_side_out else None
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    t0 = ops._pb()
+    check(lib().fosvos_vgg_forward(ctypes.byref(w), x.data_ptr(), N, H, W, ap, an, fused.data_ptr(), so, idx,
+                                   torch.cuda.current_stream(idx).cuda_stream), "vgg_forward")
+    ops._pe(t0, "vgg_forward", 2.0 * 129.114e9 * N * H * W / (480 * 854), 0.0)
+    if not keep:
+        pool.give(N, H, W, arena)
+        arena = None
+    return (outs if outs is not None else [None] * 4) + [fused], (arena, x, w, keep_alive, (N, H, W))
+
+
+def native_backward(P, packs, saved, d_outs, inplace: bool) -> Dict[str, torch.Tensor]:
+    arena, x, w, keep_alive, (N, H, W) = saved
+    dev = x.device
+    d_fused = d_outs[4]
+    d_so = list(d_outs[:4])
+    have = [g is not None for g in d_so]
+    with_so = any(have)
+    if with_so and not all(have):
+        ref = next(g for g in d_so if g is not None)
+        d_so = [g if g is not None else torch.zeros_like(ref) for g in d_so]
+    grads: Dict[str, torch.Tensor] = {}
+    if d_fused is None and not with_so:
+        return grads
+    g = VggGrads()
+    hold = []
+
+    def slot(name: str) -> int:
+        p = P[name]
+        if inplace:
+            if p.grad is None or p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            torch.autograd.graph.increment_version(p.grad)
+            return p.grad.data_ptr()
+        t = torch.empty_like(p, memory_format=torch.contiguous_format)
+        grads[name] = t
+        return t.data_ptr()
+
+    for c, (wn, bn) in enumerate(_CONV_NAMES):
+        g.conv_w[c], g.conv_b[c] = slot(wn), slot(bn)
+    for i in range(4):
+        g.side_w[i], g.side_b[i] = slot(f"side_prep.{i}.weight"), slot(f"side_prep.{i}.bias")
+    g.fuse_w, g.fuse_b = slot("fuse.weight"), slot("fuse.bias")
+    dsn_tmp = None
+    if with_so:
+        # the four score_dsn layers are separate [1,16,1,1] / [1] parameters: gather through one [4,16] / [4] scratch
+        dsn_tmp = (torch.zeros((4, 16), dtype=torch.float32, device=dev), torch.zeros((4,), dtype=torch.float32, device=dev))
+        g.dsn_w, g.dsn_b = dsn_tmp[0].data_ptr(), dsn_tmp[1].data_ptr()
+    g.accumulate = 1 if inplace else 0
+    if d_fused is not None:
+        d_fused = d_fused.contiguous().float()
+        hold.append(d_fused)
+    dso = None
+    if with_so:
+        d_so = [t.contiguous().float() for t in d_so]
+        hold += d_so
+        dso = ptr_array4([t.data_ptr() for t in d_so])
+    ap, an = _aligned_ptr(arena)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    # the dsn scratch is overwritten, never accumulated, by a separate flag-free path: run with accumulate for the
+    # parameter buffers and add the scratch afterwards
+    t0 = ops._pb()
+    check(lib().fosvos_vgg_backward(ctypes.byref(w), ctypes.byref(g), x.data_ptr(), N, H, W, ap, an,
+                                    d_fused.data_ptr() if d_fused is not None else None, dso, idx,
+                                    torch.cuda.current_stream(idx).cuda_stream), "vgg_backward")
+    ops._pe(t0, "vgg_backward", 2.0 * (2 * 129.114e9 - 0.708e9) * N * H * W / (480 * 854), 0.0)
+    if with_so:
+        for i in range(4):
+            gw, gb = dsn_tmp[0][i].reshape(1, 16, 1, 1), dsn_tmp[1][i:i + 1]
+            if inplace:
+                for name, val in ((f"score_dsn.{i}.weight", gw), (f"score_dsn.{i}.bias", gb)):
+                    p = P[name]
+                    if p.grad is None:
+                        p.grad = val.clone()
+                    else:
+                        p.grad.add_(val)
+            else:
+                grads[f"score_dsn.{i}.weight"], grads[f"score_dsn.{i}.bias"] = gw.clone(), gb.clone()
+    del hold, keep_alive
+    return grads
+
+
 class _OSVOSFunction(torch.autograd.Function):
     """One autograd node for the whole network.  Inputs: the frame and the 52 parameters in state_dict
     order; outputs: the 5 logit maps."""
@@ -254,7 +430,10 @@ class _OSVOSFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, packs: PackedWeights, with_side_out: bool, inplace: bool, x: torch.Tensor, *params: torch.Tensor):
         P = dict(zip(PARAM_NAMES, params))
-        outs, sv = forward(P, packs, x, with_side_out=with_side_out, keep=True)
+        if USE_NATIVE_LOOP:
+            outs, sv = native_forward(P, packs, packs.arenas, x, with_side_out, keep=True)
+        else:
+            outs, sv = forward(P, packs, x, with_side_out=with_side_out, keep=True)
         ctx.sv = sv
         ctx.packs = packs
         ctx.P = P
@@ -273,7 +452,12 @@ class _OSVOSFunction(torch.autograd.Function):
         d = list(d_outs)
         if not ctx.with_side_out:
             d = [None] * 4 + [d[4]]
-        grads = backward(ctx.P, ctx.packs, ctx.sv, d, inplace=ctx.inplace)
+        if USE_NATIVE_LOOP:
+            grads = native_backward(ctx.P, ctx.packs, ctx.sv, d, inplace=ctx.inplace)
+            n_, h_, w_ = ctx.sv[4]
+            ctx.packs.arenas.give(n_, h_, w_, ctx.sv[0])
+        else:
+            grads = backward(ctx.P, ctx.packs, ctx.sv, d, inplace=ctx.inplace)
         ctx.sv = None  # free the activations
         out = [None, None, None, None]
         for name in PARAM_NAMES:
@@ -291,7 +475,10 @@ def run(packs: PackedWeights, params: Sequence[torch.Tensor], x: torch.Tensor, w
     autograd node; otherwise (inference) nothing is kept."""
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         return list(_OSVOSFunction.apply(packs, with_side_out, inplace_grad, x, *params))
-    outs, _ = forward(dict(zip(PARAM_NAMES, params)), packs, x, with_side_out=with_side_out, keep=False)
+    if USE_NATIVE_LOOP:
+        outs, _ = native_forward(dict(zip(PARAM_NAMES, params)), packs, packs.arenas, x, with_side_out, keep=False)
+    else:
+        outs, _ = forward(dict(zip(PARAM_NAMES, params)), packs, x, with_side_out=with_side_out, keep=False)
     if not with_side_out:
         outs = [torch.empty(0, device=x.device) for _ in range(4)] + [outs[4]]
     return outs

@@ -63,10 +63,23 @@ class OSVOS_VGG(nn.Module):
     # ------------------------------------------------------------------ forward on the HIP kernels
     def forward(self, x):
         """list of 5 logit maps [N,1,H,W]: the 4 side outputs then the fused output."""
-        sd = dict(self.named_parameters())
-        params = [sd[name] for name in engine.PARAM_NAMES]
+        params = self._ordered_params()
         return engine.run(self._packs, params, x, with_side_out=True,
                           inplace_grad=getattr(self, 'accumulate_grads_in_place', False))
+
+    def _ordered_params(self):
+        """The 52 parameters in state_dict order, by direct attribute access (named_parameters() walks the whole
+        module tree: 0.15 ms per call)."""
+        ps = [m.weight for m in self.upscale] + [m.weight for m in self.upscale_]
+        for stage in self.stages:
+            for m in stage:
+                if isinstance(m, nn.Conv2d):
+                    ps += [m.weight, m.bias]
+        for mods in (self.side_prep, self.score_dsn):
+            for m in mods:
+                ps += [m.weight, m.bias]
+        ps += [self.fuse.weight, self.fuse.bias]
+        return ps
 
     def __getstate__(self):
         state = self.__dict__.copy()

@@ -65,6 +65,8 @@ class FlatGrads:
     """All trainable gradients as views of one flat fp32 buffer."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
+        params = list(params)
+        # re-use the buffer a previous loop already attached to these parameters
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatGrads: no trainable parameters")

@@ -79,7 +79,9 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     net.accumulate_grads_in_place = True  # this loop only ever calls loss.backward()
     world = parallel.world_size() if data_parallel else 1
     local_accum = parallel.split_accumulation(avg_grad_every_n, world)
-    flat = parallel.FlatGrads(net.parameters()) if world > 1 else None
+    # gradients live in one flat fp32 buffer: the wgrad kernels accumulate straight into it, zeroing is one memset,
+    # and under data parallelism it is the single all-reduce payload
+    flat = parallel.FlatGrads(net.parameters())
 
     n_samples = len(dataloader)
     loss_tr = []
@@ -116,13 +118,10 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             n_iters += 1
 
             if counter_gradient % local_accum == 0:
-                if flat is not None:
+                if world > 1:
                     flat.all_reduce()
                 optimizer.step()
-                if flat is not None:
-                    flat.zero()
-                else:
-                    optimizer.zero_grad()
+                flat.zero()
                 counter_gradient = 0
 
         if (epoch % snapshot_every_n) == snapshot_every_n - 1 and parallel.rank() == 0:

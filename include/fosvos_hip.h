@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 1
+#define FOSVOS_ABI_VERSION 2
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -183,6 +183,52 @@ typedef struct fosvos_sgd_entry {
 } fosvos_sgd_entry;
 int fosvos_sgd_momentum_step(const fosvos_sgd_entry *table, int n_tensors, int64_t max_numel, float momentum,
                              int first_step, int device, void *stream);
+
+/* ---- whole-network entry points ------------------------------------------------------------------
+ * The reference drives ~60 torch.nn calls per forward from Python (src/networks/osvos_vgg.py:61-83) and
+ * autograd replays them backward.  Here the layer loop itself is native: ONE call issues every kernel of
+ * OSVOS_VGG.forward, ONE call every kernel of its backward, over a caller-provided arena (activations,
+ * activation gradients, op workspaces; layout private to the library, size from fosvos_vgg_arena_bytes).
+ * The structs hold device pointers only and live in HOST memory for the duration of the call.
+ * Conv index c = 0..12 runs conv1_1 .. conv5_3; side index i = 0..3 hangs off stages 2..5.
+ * replaces: OSVOS_VGG.forward and its autograd graph. */
+typedef struct fosvos_vgg_weights {
+    const float *conv_w[13];      /* fp32 OIHW masters (only conv_w[0] is read by a kernel; the rest via images) */
+    const float *conv_b[13];      /* fp32 [Co] */
+    const uint16_t *conv_wf[13];  /* packed forward images ([0] unused) */
+    const uint16_t *conv_wd[13];  /* packed dgrad images  ([0] unused) */
+    const float *side_b[4];
+    const uint16_t *side_wf[4];
+    const uint16_t *side_wd[4];
+    const float *filt[4];         /* [k][k][16] per-channel deconv filters */
+    const float *filt1[4];        /* [k][k] */
+    const float *dsn_w;           /* [4][16] */
+    const float *dsn_b;           /* [4] */
+    const float *fuse_w;          /* [64] */
+    const float *fuse_b;          /* [1] */
+} fosvos_vgg_weights;
+
+typedef struct fosvos_vgg_grads {
+    float *conv_w[13];            /* fp32 OIHW */
+    float *conv_b[13];
+    float *side_w[4];             /* [16,C,3,3] */
+    float *side_b[4];
+    float *dsn_w;                 /* [4][16] or NULL when no side-output gradient flows */
+    float *dsn_b;                 /* [4] or NULL */
+    float *fuse_w;                /* [64] */
+    float *fuse_b;                /* [1] */
+    int accumulate;               /* != 0: add into the buffers (gradient accumulation), else overwrite */
+} fosvos_vgg_grads;
+
+size_t fosvos_vgg_arena_bytes(int N, int H, int W);
+/* fused: [N,1,H,W] fp32; side_out: four [N,1,H,W] fp32 buffers or NULL.  The arena keeps what backward needs. */
+int fosvos_vgg_forward(const fosvos_vgg_weights *w, const float *frame, int N, int H, int W, void *arena,
+                       size_t arena_bytes, float *fused, float *const side_out[4], int device, void *stream);
+/* d_fused / d_side_out: upstream gradients ([N,1,H,W] fp32; d_fused or all four d_side_out may be NULL).
+ * Must follow a fosvos_vgg_forward on the same arena, frame and shape. */
+int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg_grads *g, const float *frame, int N, int H, int W,
+                        void *arena, size_t arena_bytes, const float *d_fused, const float *const d_side_out[4],
+                        int device, void *stream);
 
 #ifdef __cplusplus
 }
