@@ -5,6 +5,8 @@
 //
 // Why native: driven from Python, each of the ~100 ops of a training step costs ~19 us of interpreter, ctypes
 // marshalling and allocator time (1.8 ms/step - as much as the GPU needs); from C++ a launch costs ~3 us.
+#include <mutex>
+
 #include "common.hpp"
 
 using namespace fosvos;
@@ -28,7 +30,8 @@ struct Arena {
     size_t gpooled[4];       // gradients wrt them
     size_t side[4];          // fp32 NHWC [N,h,w,16]
     size_t dside[4];         // bf16 NHWC [N,h,w,32]
-    size_t ws, ws_bytes;     // shared op workspace
+    size_t ws, ws_bytes;     // op workspace of the main stream (split-K slabs, head backward)
+    size_t wsa, wsa_bytes;   // op workspace of the wgrad (auxiliary) stream
     size_t total;
 };
 
@@ -51,23 +54,46 @@ Arena make_arena(int N, int H, int W) {
         a.side[s - 1] = take((size_t)N * a.sh[s] * a.sw[s] * 16 * 4);
         a.dside[s - 1] = take((size_t)N * a.sh[s] * a.sw[s] * 32 * 2);
     }
-    size_t ws = fosvos_conv3x3_first_wgrad_workspace_bytes(N, H, W, 64);
-    ws = std::max(ws, fosvos_head_bwd_workspace_bytes(N, H, W));
+    size_t ws = fosvos_head_bwd_workspace_bytes(N, H, W);
+    size_t wsa = fosvos_conv3x3_first_wgrad_workspace_bytes(N, H, W, 64);
     for (int c = 1; c < kNConv; ++c) {
         const int s = kStageOf[c];
-        ws = std::max(ws, fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kCin[c], kCout[c]));
+        wsa = std::max(wsa, fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kCin[c], kCout[c]));
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kCin[c], kCout[c]));   // fwd split-K
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kCout[c], kCin[c]));   // dgrad split-K
     }
     for (int s = 1; s < 5; ++s) {
-        ws = std::max(ws, fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16));
+        wsa = std::max(wsa, fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16));
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16));
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], 16, kStageCh[s]));
     }
     a.ws_bytes = up256(ws);
     a.ws = take(a.ws_bytes);
+    a.wsa_bytes = up256(wsa);
+    a.wsa = take(a.wsa_bytes);
     a.total = off;
     return a;
+}
+
+// ---- the library's only persistent state: timing-disabled events for the two-stream backward
+constexpr int kNEvents = 16;  // 13 conv-output gradients + head + fork + join
+struct EventPool {
+    hipEvent_t ev[kNEvents];
+    bool ready = false;
+};
+EventPool g_events[16];  // per device
+std::mutex g_events_mutex;
+
+int get_events(int device, hipEvent_t **out) {
+    FOSVOS_REQUIRE(device >= 0 && device < 16, FOSVOS_E_ARG, "vgg_backward: device index %d out of range", device);
+    std::lock_guard<std::mutex> lock(g_events_mutex);
+    EventPool &p = g_events[device];
+    if (!p.ready) {
+        for (int i = 0; i < kNEvents; ++i) FOSVOS_HIP_CHECK(hipEventCreateWithFlags(&p.ev[i], hipEventDisableTiming));
+        p.ready = true;
+    }
+    *out = p.ev;
+    return FOSVOS_OK;
 }
 
 #define FOSVOS_TRY(expr)          \
@@ -132,7 +158,7 @@ extern "C" int fosvos_vgg_forward(const fosvos_vgg_weights *w, const float *fram
 
 extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg_grads *g, const float *frame, int N,
                                    int H, int W, void *arena, size_t arena_bytes, const float *d_fused,
-                                   const float *const d_side_out[4], int device, void *stream) {
+                                   const float *const d_side_out[4], int device, void *stream, void *aux_stream) {
     const Arena a = make_arena(N, H, W);
     FOSVOS_TRY(check_net(w, frame, arena, N, H, W, arena_bytes, a, "vgg_backward"));
     FOSVOS_REQUIRE(g, FOSVOS_E_ARG, "vgg_backward: null gradient table");
@@ -142,7 +168,28 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
     auto act = [&](int c) { return reinterpret_cast<uint16_t *>(base + a.act[c]); };
     auto gact = [&](int c) { return reinterpret_cast<uint16_t *>(base + a.gact[c]); };
     void *ws = base + a.ws;
+    void *wsa = base + a.wsa;
     const int acc = g->accumulate ? 1 : 0;
+
+    // ---- two streams: data-gradient chain on `stream`, weight gradients on `aux_stream`
+    hipStream_t sm = (hipStream_t)stream;
+    const bool par = aux_stream != nullptr && aux_stream != stream;
+    hipStream_t sa = par ? (hipStream_t)aux_stream : sm;
+    hipEvent_t *ev = nullptr;
+    if (par) {
+        FOSVOS_ENTER(device);
+        FOSVOS_TRY(get_events(device, &ev));
+        // fork: the wgrad stream may not run ahead of what `stream` has queued (the forward pass, the loss)
+        FOSVOS_HIP_CHECK(hipEventRecord(ev[14], sm));
+        FOSVOS_HIP_CHECK(hipStreamWaitEvent(sa, ev[14], 0));
+    }
+    // "tensor e is complete on the main stream": lets the wgrad stream consume it
+    auto publish = [&](int e) -> int {
+        if (!par) return FOSVOS_OK;
+        FOSVOS_HIP_CHECK(hipEventRecord(ev[e], sm));
+        FOSVOS_HIP_CHECK(hipStreamWaitEvent(sa, ev[e], 0));
+        return FOSVOS_OK;
+    };
 
     // ---- head: d_side[i], fuse / score_dsn gradients
     const float *side[4];
@@ -157,41 +204,48 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
     FOSVOS_TRY(head_bwd_impl(side, hs, wsz, w->filt, with_so ? w->filt1 : nullptr, with_so ? w->dsn_w : nullptr, w->fuse_w,
                              d_fused, with_so ? d_side_out : nullptr, dside, g->fuse_w, g->fuse_b,
                              with_so ? g->dsn_w : nullptr, with_so ? g->dsn_b : nullptr, N, H, W, acc, ws, a.ws_bytes, device,
-                             stream));
+                             sm));
+    FOSVOS_TRY(publish(13));  // d_side ready
 
     // ---- stages 4..0
     for (int s = 4; s >= 0; --s) {
         const int hh = a.sh[s], ww = a.sw[s], last = kLastOfStage[s], first = kFirstOfStage[s];
         if (s > 0) {
-            // side_prep[s-1]: wgrad from (stage output, d_side), then its dgrad into the stage-output gradient:
-            // ReLU-masked and added to what already came back through the next stage's pool (already in gact[last])
+            // side_prep[s-1]: wgrad from (stage output, d_side) on the wgrad stream; its dgrad into the stage-output
+            // gradient: ReLU-masked and added to what came back through the next stage's pool (already in gact[last])
             FOSVOS_TRY(fosvos_conv3x3_wgrad(act(last), dside[s - 1], g->side_w[s - 1], g->side_b[s - 1], N, hh, ww,
-                                            kStageCh[s], 16, acc, ws, a.ws_bytes, device, stream));
+                                            kStageCh[s], 16, acc, wsa, a.wsa_bytes, device, sa));
             const uint16_t *addend = (s < 4) ? gact(last) : nullptr;
             FOSVOS_TRY(fosvos_conv3x3_dgrad(dside[s - 1], w->side_wd[s - 1], act(last), addend, gact(last), N, hh, ww,
-                                            kStageCh[s], 16, ws, a.ws_bytes, device, stream));
+                                            kStageCh[s], 16, ws, a.ws_bytes, device, sm));
         }
+        FOSVOS_TRY(publish(last));  // gradient wrt the stage output is complete
         for (int c = last; c >= first; --c) {
             if (c == 0) {
-                FOSVOS_TRY(first_wgrad_impl(frame, gact(0), g->conv_w[0], g->conv_b[0], N, H, W, kCout[0], acc, ws,
-                                            a.ws_bytes, device, stream));
+                FOSVOS_TRY(first_wgrad_impl(frame, gact(0), g->conv_w[0], g->conv_b[0], N, H, W, kCout[0], acc, wsa,
+                                            a.wsa_bytes, device, sa));
                 break;
             }
-            const bool from_pool = (c == first);  // its input is the pool output (s >= 1) - conv 1 reads conv 0
-            const uint16_t *xin = from_pool && s > 0 ? reinterpret_cast<const uint16_t *>(base + a.pooled[s - 1]) : act(c - 1);
-            FOSVOS_TRY(fosvos_conv3x3_wgrad(xin, gact(c), g->conv_w[c], g->conv_b[c], N, hh, ww, kCin[c], kCout[c], acc, ws,
-                                            a.ws_bytes, device, stream));
+            const bool from_pool = (c == first) && s > 0;  // its input is the pool output; conv 1 reads conv 0
+            const uint16_t *xin = from_pool ? reinterpret_cast<const uint16_t *>(base + a.pooled[s - 1]) : act(c - 1);
+            FOSVOS_TRY(fosvos_conv3x3_wgrad(xin, gact(c), g->conv_w[c], g->conv_b[c], N, hh, ww, kCin[c], kCout[c], acc, wsa,
+                                            a.wsa_bytes, device, sa));
             // dgrad: into the previous conv's output gradient (masked by its ReLU), or into the pool-output gradient
             // (unmasked: the pool backward applies the producer's mask)
-            uint16_t *dx = from_pool && s > 0 ? reinterpret_cast<uint16_t *>(base + a.gpooled[s - 1]) : gact(c - 1);
-            const uint16_t *mask = from_pool && s > 0 ? nullptr : act(c - 1);
+            uint16_t *dx = from_pool ? reinterpret_cast<uint16_t *>(base + a.gpooled[s - 1]) : gact(c - 1);
+            const uint16_t *mask = from_pool ? nullptr : act(c - 1);
             FOSVOS_TRY(fosvos_conv3x3_dgrad(gact(c), w->conv_wd[c], mask, nullptr, dx, N, hh, ww, kCin[c], kCout[c], ws,
-                                            a.ws_bytes, device, stream));
+                                            a.ws_bytes, device, sm));
+            if (!from_pool) FOSVOS_TRY(publish(c - 1));
         }
         if (s > 0)  // pool backward into the previous stage's output gradient, its ReLU mask fused
             FOSVOS_TRY(fosvos_maxpool2x2_ceil_bwd(act(kLastOfStage[s - 1]), reinterpret_cast<const uint16_t *>(base + a.gpooled[s - 1]),
                                                   gact(kLastOfStage[s - 1]), N, a.sh[s - 1], a.sw[s - 1], kStageCh[s - 1], 1,
-                                                  device, stream));
+                                                  device, sm));
+    }
+    if (par) {  // join: everything after this call on `stream` sees the weight gradients
+        FOSVOS_HIP_CHECK(hipEventRecord(ev[15], sa));
+        FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[15], 0));
     }
     return FOSVOS_OK;
 }

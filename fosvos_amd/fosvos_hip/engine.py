@@ -276,6 +276,18 @@ class ArenaPool:
 
     def __init__(self) -> None:
         self._free: Dict[Tuple[int, int, int, int], List[torch.Tensor]] = {}
+        self._aux: Dict[int, "torch.cuda.Stream"] = {}
+
+    def aux_stream(self, device_index: int) -> int:
+        """Handle of the auxiliary HIP stream the backward pass issues its weight-gradient kernels on
+        (FOSVOS_TWO_STREAMS=0 disables it)."""
+        if os.environ.get("FOSVOS_TWO_STREAMS", "1") == "0":
+            return 0
+        st = self._aux.get(device_index)
+        if st is None:
+            st = torch.cuda.Stream(device=device_index)
+            self._aux[device_index] = st
+        return st.cuda_stream
 
     def take(self, n: int, h: int, w: int, device: torch.device) -> torch.Tensor:
         key = (n, h, w, device.index if device.index is not None else torch.cuda.current_device())
@@ -405,7 +417,8 @@ def native_backward(P, packs, saved, d_outs, inplace: bool) -> Dict[str, torch.T
     t0 = ops._pb()
     check(lib().fosvos_vgg_backward(ctypes.byref(w), ctypes.byref(g), x.data_ptr(), N, H, W, ap, an,
                                     d_fused.data_ptr() if d_fused is not None else None, dso, idx,
-                                    torch.cuda.current_stream(idx).cuda_stream), "vgg_backward")
+                                    torch.cuda.current_stream(idx).cuda_stream, packs.arenas.aux_stream(idx) or None),
+          "vgg_backward")
     ops._pe(t0, "vgg_backward", 2.0 * (2 * 129.114e9 - 0.708e9) * N * H * W / (480 * 854), 0.0)
     if with_so:
         for i in range(4):

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 2
+#define FOSVOS_ABI_VERSION 3
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -225,10 +225,15 @@ size_t fosvos_vgg_arena_bytes(int N, int H, int W);
 int fosvos_vgg_forward(const fosvos_vgg_weights *w, const float *frame, int N, int H, int W, void *arena,
                        size_t arena_bytes, float *fused, float *const side_out[4], int device, void *stream);
 /* d_fused / d_side_out: upstream gradients ([N,1,H,W] fp32; d_fused or all four d_side_out may be NULL).
- * Must follow a fosvos_vgg_forward on the same arena, frame and shape. */
+ * Must follow a fosvos_vgg_forward on the same arena, frame and shape.
+ * aux_stream (a second hipStream_t of the same device, or NULL): when given, every weight-gradient kernel is
+ * issued on it while the data-gradient chain stays on `stream`; the two are ordered by events (a layer's wgrad
+ * waits for that layer's output gradient; `stream` waits for the last wgrad before the call's work is complete
+ * in stream order), so the caller sees ordinary single-stream semantics on `stream`.  The events are the one
+ * piece of persistent state the library keeps (16 timing-disabled hipEvents per device, created on first use). */
 int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg_grads *g, const float *frame, int N, int H, int W,
                         void *arena, size_t arena_bytes, const float *d_fused, const float *const d_side_out[4],
-                        int device, void *stream);
+                        int device, void *stream, void *aux_stream);
 
 #ifdef __cplusplus
 }
