@@ -243,7 +243,7 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
                                                   gact(kLastOfStage[s - 1]), N, a.sh[s - 1], a.sw[s - 1], kStageCh[s - 1], 1,
                                                   device, sm));
     }
-    if (par) {  // join: everything after this call on `stream` sees the weight gradients
+    if (par && !g->defer_join) {  // join: everything after this call on `stream` sees the weight gradients
         FOSVOS_HIP_CHECK(hipEventRecord(ev[15], sa));
         FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[15], 0));
     }

@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 CONV_RELU = 1
 CONV_OUT_F32 = 2
 
@@ -45,7 +45,7 @@ class VggGrads(ctypes.Structure):
     """fosvos_vgg_grads."""
     _fields_ = [("conv_w", _P13), ("conv_b", _P13), ("side_w", _P4), ("side_b", _P4),
                 ("dsn_w", c_void_p), ("dsn_b", c_void_p), ("fuse_w", c_void_p), ("fuse_b", c_void_p),
-                ("accumulate", c_int)]
+                ("accumulate", c_int), ("defer_join", c_int)]
 
 # name -> (restype, argtypes); every entry point of include/fosvos_hip.h
 SIGNATURES = {

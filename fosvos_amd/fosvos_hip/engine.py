@@ -277,6 +277,7 @@ class ArenaPool:
     def __init__(self) -> None:
         self._free: Dict[Tuple[int, int, int, int], List[torch.Tensor]] = {}
         self._aux: Dict[int, "torch.cuda.Stream"] = {}
+        self._pending: List[Tuple[int, int, int, torch.Tensor]] = []  # arenas still read by deferred wgrad kernels
 
     def aux_stream(self, device_index: int) -> int:
         """Handle of the auxiliary HIP stream the backward pass issues its weight-gradient kernels on
@@ -296,6 +297,17 @@ class ArenaPool:
             return free.pop()
         nbytes = lib().fosvos_vgg_arena_bytes(n, h, w)
         return torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+
+    def hold(self, n: int, h: int, w: int, arena: torch.Tensor) -> None:
+        self._pending.append((n, h, w, arena))
+
+    def join(self) -> None:
+        """Make the current stream wait for every deferred weight-gradient kernel, then recycle their arenas."""
+        for idx, st in self._aux.items():
+            torch.cuda.current_stream(idx).wait_stream(st)
+        for n, h, w, arena in self._pending:
+            self.give(n, h, w, arena)
+        self._pending.clear()
 
     def give(self, n: int, h: int, w: int, arena: torch.Tensor) -> None:
         key = (n, h, w, arena.device.index)
@@ -364,7 +376,7 @@ def native_forward(P, packs, pool: ArenaPool, x: torch.Tensor, with_side_out: bo
     return (outs if outs is not None else [None] * 4) + [fused], (arena, x, w, keep_alive, (N, H, W))
 
 
-def native_backward(P, packs, saved, d_outs, inplace: bool) -> Dict[str, torch.Tensor]:
+def native_backward(P, packs, saved, d_outs, inplace: bool, defer_join: bool = False) -> Dict[str, torch.Tensor]:
     arena, x, w, keep_alive, (N, H, W) = saved
     dev = x.device
     d_fused = d_outs[4]
@@ -402,6 +414,8 @@ def native_backward(P, packs, saved, d_outs, inplace: bool) -> Dict[str, torch.T
         dsn_tmp = (torch.zeros((4, 16), dtype=torch.float32, device=dev), torch.zeros((4,), dtype=torch.float32, device=dev))
         g.dsn_w, g.dsn_b = dsn_tmp[0].data_ptr(), dsn_tmp[1].data_ptr()
     g.accumulate = 1 if inplace else 0
+    aux = packs.arenas.aux_stream(dev.index if dev.index is not None else torch.cuda.current_device())
+    g.defer_join = 1 if (defer_join and inplace and aux) else 0
     if d_fused is not None:
         d_fused = d_fused.contiguous().float()
         hold.append(d_fused)
@@ -417,7 +431,7 @@ def native_backward(P, packs, saved, d_outs, inplace: bool) -> Dict[str, torch.T
     t0 = ops._pb()
     check(lib().fosvos_vgg_backward(ctypes.byref(w), ctypes.byref(g), x.data_ptr(), N, H, W, ap, an,
                                     d_fused.data_ptr() if d_fused is not None else None, dso, idx,
-                                    torch.cuda.current_stream(idx).cuda_stream, packs.arenas.aux_stream(idx) or None),
+                                    torch.cuda.current_stream(idx).cuda_stream, aux or None),
           "vgg_backward")
     ops._pe(t0, "vgg_backward", 2.0 * (2 * 129.114e9 - 0.708e9) * N * H * W / (480 * 854), 0.0)
     if with_so:
@@ -433,6 +447,10 @@ def native_backward(P, packs, saved, d_outs, inplace: bool) -> Dict[str, torch.T
             else:
                 grads[f"score_dsn.{i}.weight"], grads[f"score_dsn.{i}.bias"] = gw.clone(), gb.clone()
     del hold, keep_alive
+    if g.defer_join:
+        packs.arenas.hold(N, H, W, arena)
+    else:
+        packs.arenas.give(N, H, W, arena)
     return grads
 
 
@@ -466,9 +484,8 @@ class _OSVOSFunction(torch.autograd.Function):
         if not ctx.with_side_out:
             d = [None] * 4 + [d[4]]
         if USE_NATIVE_LOOP:
-            grads = native_backward(ctx.P, ctx.packs, ctx.sv, d, inplace=ctx.inplace)
-            n_, h_, w_ = ctx.sv[4]
-            ctx.packs.arenas.give(n_, h_, w_, ctx.sv[0])
+            grads = native_backward(ctx.P, ctx.packs, ctx.sv, d, inplace=ctx.inplace,
+                                    defer_join=getattr(ctx.packs, "defer_wgrad_join", False))
         else:
             grads = backward(ctx.P, ctx.packs, ctx.sv, d, inplace=ctx.inplace)
         ctx.sv = None  # free the activations

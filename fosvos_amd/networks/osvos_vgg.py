@@ -67,6 +67,22 @@ class OSVOS_VGG(nn.Module):
         return engine.run(self._packs, params, x, with_side_out=True,
                           inplace_grad=getattr(self, 'accumulate_grads_in_place', False))
 
+    def join_gradients(self):
+        """With ``defer_wgrad_join`` the weight-gradient kernels of a backward pass may still be running on the
+        auxiliary stream when ``backward()`` returns; call this before reading ``p.grad`` (optimizer step,
+        all-reduce).  No-op otherwise."""
+        self._packs.arenas.join()
+
+    @property
+    def defer_wgrad_join(self):
+        return getattr(self._packs, "defer_wgrad_join", False)
+
+    @defer_wgrad_join.setter
+    def defer_wgrad_join(self, value):
+        if not value:
+            self._packs.arenas.join()
+        self._packs.defer_wgrad_join = bool(value)
+
     def _ordered_params(self):
         """The 52 parameters in state_dict order, by direct attribute access (named_parameters() walks the whole
         module tree: 0.15 ms per call)."""

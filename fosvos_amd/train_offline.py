@@ -4,6 +4,7 @@ Same entry points and loop semantics (src/train_offline.py:77-110): five deeply-
 ``loss = (1 - epoch / n_epochs) * sum(side losses) + fused loss``, ``loss /= avg_grad_every_n``,
 backward, step every ``avg_grad_every_n``-th iteration; snapshots every ``snapshot_every_n`` epochs.
 """
+import os
 import timeit
 from pathlib import Path
 
@@ -69,6 +70,8 @@ def _train(net_provider: NetworkProvider, data_loader_train, data_loader_test, o
     log.info('Start of offline training')
     net = net_provider.network
     net.accumulate_grads_in_place = True  # this loop only ever calls loss.backward()
+    # weights are constant inside an accumulation cycle: let the next forward overlap the wgrad tail of this backward
+    net.defer_wgrad_join = os.environ.get('FOSVOS_DEFER_JOIN', '1') != '0'
     world = parallel.world_size() if data_parallel else 1
     local_accum = parallel.split_accumulation(avg_grad_every_n, world)
     # gradients live in one flat fp32 buffer: the wgrad kernels accumulate straight into it, zeroing is one memset,
@@ -104,6 +107,7 @@ def _train(net_provider: NetworkProvider, data_loader_train, data_loader_test, o
             n_iters += 1
 
             if counter_gradient % local_accum == 0:
+                net.join_gradients()
                 if world > 1:
                     flat.all_reduce()
                 optimizer.step()
@@ -125,6 +129,7 @@ def _train(net_provider: NetworkProvider, data_loader_train, data_loader_test, o
                 log.info('***Testing *** Loss %d: %f' % (l, vals[l]))
 
     summary_writer.close()
+    net.defer_wgrad_join = False  # joins
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     return {'loss_train': loss_train, 'loss_test': loss_test, 'iterations': n_iters,

@@ -11,6 +11,7 @@ Run:  python train_online.py --synthetic --n-epochs 100        (one GPU)
       torchrun --nproc-per-node 8 train_online.py --synthetic --data-parallel --avg-grad-every-n 8
 """
 import sys
+import os
 import timeit
 from pathlib import Path
 from typing import Optional
@@ -77,6 +78,8 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     log.info('Start of Online Training, sequence: ' + seq_name)
     net = net_provider.network
     net.accumulate_grads_in_place = True  # this loop only ever calls loss.backward()
+    # weights are constant inside an accumulation cycle: let the next forward overlap the wgrad tail of this backward
+    net.defer_wgrad_join = os.environ.get('FOSVOS_DEFER_JOIN', '1') != '0'
     world = parallel.world_size() if data_parallel else 1
     local_accum = parallel.split_accumulation(avg_grad_every_n, world)
     # gradients live in one flat fp32 buffer: the wgrad kernels accumulate straight into it, zeroing is one memset,
@@ -118,6 +121,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             n_iters += 1
 
             if counter_gradient % local_accum == 0:
+                net.join_gradients()
                 if world > 1:
                     flat.all_reduce()
                 optimizer.step()
@@ -127,6 +131,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         if (epoch % snapshot_every_n) == snapshot_every_n - 1 and parallel.rank() == 0:
             net_provider.save_model(epoch, sequence=seq_name)
 
+    net.defer_wgrad_join = False  # joins
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     time_for_all = timeit.default_timer() - time_all_start

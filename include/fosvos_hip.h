@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 3
+#define FOSVOS_ABI_VERSION 4
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -218,6 +218,10 @@ typedef struct fosvos_vgg_grads {
     float *fuse_w;                /* [64] */
     float *fuse_b;                /* [1] */
     int accumulate;               /* != 0: add into the buffers (gradient accumulation), else overwrite */
+    int defer_join;               /* != 0 with an aux_stream: do NOT make `stream` wait for the weight gradients at the
+                                   * end of the call; the caller joins (stream waits on aux_stream) before it reads
+                                   * them, and must not reuse this arena before that.  Lets the next forward pass
+                                   * (other arena, same weights) overlap the tail of the weight-gradient kernels. */
 } fosvos_vgg_grads;
 
 size_t fosvos_vgg_arena_bytes(int N, int H, int W);

@@ -191,6 +191,31 @@ def test_inplace_grad_accumulation_matches_autograd():
         assert (a - b).abs().max().item() <= 1e-6 * a.abs().max().item() + 1e-30, k_
 
 
+def test_two_stream_deferred_join_is_bit_identical():
+    """The auxiliary-stream weight gradients with the join deferred over several micro-batches (what the training
+    loops do) equal the single-stream result bit for bit: same kernels, same fixed-order reductions."""
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    frames = [O.synthetic_frame(1, 48, 86, seed=41), O.synthetic_frame(1, 40, 70, seed=42)]
+    res = []
+    for mode in ("single", "deferred"):
+        os.environ["FOSVOS_TWO_STREAMS"] = "0" if mode == "single" else "1"
+        try:
+            net, _ = make_net(13)
+            net.accumulate_grads_in_place = True
+            net.defer_wgrad_join = mode == "deferred"
+            for it in range(4):
+                x, gt = frames[it % 2]
+                (cbce(net(x.to(DEV))[-1], gt.to(DEV), size_average=False) / 4).backward()
+            net.join_gradients()
+            torch.cuda.synchronize()
+            res.append({n_: p.grad.clone() for n_, p in net.named_parameters() if p.grad is not None})
+        finally:
+            os.environ.pop("FOSVOS_TWO_STREAMS", None)
+    assert res[0].keys() == res[1].keys() and len(res[0]) > 30
+    for k_ in res[0]:
+        assert torch.equal(res[0][k_], res[1][k_]), k_
+
+
 def test_offline_loop_vs_golden(golden):
     from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
     from util.network_provider import VGGOfflineProvider
