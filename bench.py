@@ -214,6 +214,19 @@ def main():
         conv_calls = sum(a["calls"] for a in conv) / n_prof
         conv_flop = sum(a["flops"] for a in conv) / n_prof
         achieved = conv_flop / (conv_ms * 1e-3) / 1e12
+        # HBM bytes per launch of the same kernel family from the committed PMC passes (rocprofv3 cannot run inside
+        # this process); null when no summary is present
+        traffic, traffic_note = None, "no profiles/*_pmc_traffic.json present"
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+            if cands:
+                pm = json.load(open(cands[-1]))
+                traffic = pm["summary"]["conv_mfma_family"]["hbm_bytes_per_launch"]
+                traffic_note = (f"bytes/launch, conv MFMA family, from {os.path.relpath(cands[-1], ROOT)}: {pm['source']}; "
+                                f"{pm['corrections']}")
+        except Exception as e:  # a malformed summary must not break the bench line
+            traffic_note = f"could not read PMC summary: {e}"
         out["roofline"] = {
             "bound": "mfma",
             "kernel": "conv3x3 implicit-GEMM family (k_conv3x3_igemm fwd+dgrad, k_wgrad), bf16 MFMA 16x16x32",
@@ -221,7 +234,8 @@ def main():
             "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_note": traffic_note,
             "launches_per_step": conv_calls,
             "algorithmic_gflop_per_step": conv_flop / 1e9,
             "avg_launch_us": conv_ms / conv_calls * 1000.0,

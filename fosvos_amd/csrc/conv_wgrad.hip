@@ -278,9 +278,10 @@ __global__ __launch_bounds__(256) void k_wgrad_final(const float *__restrict__ s
     }
 }
 
-// k_wgrad<64> holds 144 accumulators + the prefetched tile: one workgroup per CU.  One full wave of
-// workgroups (256 CUs) keeps the slab traffic (splits x |dw|) minimal.
-constexpr int kTargetBlocks = 256;
+// Workgroups per launch.  Slab traffic = workgroups x block bytes, and the wgrad kernels run on the auxiliary
+// stream BESIDE the dgrad chain (vgg_net.hip), so they need not fill the chip alone: 128 fat workgroups halve the
+// slab bytes of 256 at the same step time; 64 make the auxiliary stream the critical path (measured).
+constexpr int kTargetBlocks = 128;
 constexpr int kMainBCO = 64;  // co block of the main instantiation: 2 co fragments x 9 taps = 72 accumulator VGPRs
 
 struct Plan {
