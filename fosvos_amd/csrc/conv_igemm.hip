@@ -36,7 +36,25 @@ struct ConvArgs {
     int k_splits;      // > 1: blockIdx.z owns a range of K chunks and writes raw fp32 partials
     int chunks_per_split;
     float *partial;    // [k_splits][N*H*W][Cout] fp32 when k_splits > 1
+#ifdef FOSVOS_STAMP
+    unsigned long long *stamps;  // diagnostic build only (tools/igemm_lab.hip): 16 slots per workgroup
+#endif
 };
+
+#ifdef FOSVOS_STAMP
+unsigned long long *g_stamps = nullptr;
+#define FOSVOS_STAMP_AT(i)                                                                               \
+    if (a.stamps && threadIdx.x == 0)                                                                    \
+        a.stamps[((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) << 4) + (i)] = \
+            __builtin_amdgcn_s_memtime();
+#define FOSVOS_STAMP_RT(i)                                                                               \
+    if (a.stamps && threadIdx.x == 0)                                                                    \
+        a.stamps[((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) << 4) + (i)] = \
+            __builtin_amdgcn_s_memrealtime();
+#else
+#define FOSVOS_STAMP_AT(i)
+#define FOSVOS_STAMP_RT(i)
+#endif
 
 template <int TH_, int TW_, int BN_, int WM_, int WN_>
 struct Tile {
@@ -56,15 +74,52 @@ struct Tile {
     static constexpr int LDS_MAIN = (A_SLOTS + B_SLOTS) * 16;
     static constexpr int LDS_OUT = BM * OUT_LD * 2;
     static constexpr int LDS_BYTES = LDS_MAIN > LDS_OUT ? LDS_MAIN : LDS_OUT;
+#ifndef FOSVOS_MID_WPE
+#define FOSVOS_MID_WPE 3
+#endif
+    // resident workgroups per CU (= waves per SIMD): what 160 KB of LDS allows, at most 2 for the 256-px tiles
+    static constexpr int WPE = (BM >= 256 || BN < 64) ? 2 : FOSVOS_MID_WPE;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(TW % 16 == 0 && WAVE_M % 16 == 0 && WAVE_N % 16 == 0, "fragment alignment");
     static_assert(BM % WM == 0 && BN % WN == 0, "wave split");
 };
 
+// Scheduling of one tap of the MFMA loop (row-major over the MF pixel fragments).  After row i the register of
+// pixel fragment i is dead, so the same row of the NEXT tap is read into it, and the next tap's weight fragments
+// (second register set) are read behind the first rows; the prefetch loads of the next chunk ride in the last rows.
+//   row i : NF MFMAs | 1 + nb(i) LDS reads | (1 global load)
+// sched_group_barrier masks (LLVM AMDGPU): 0x008 MFMA, 0x020 VMEM read, 0x100 DS read.
+template <int MF, int NF>
+struct TapPlan {
+    static constexpr int rows_b = MF / 2 > 0 ? MF / 2 : 1;      // rows that carry weight-fragment reads
+    static constexpr int per_row = (NF + rows_b - 1) / rows_b;  // weight fragments read behind one such row
+    static constexpr int nb(int i) {
+        const int left = NF - i * per_row;
+        return left <= 0 ? 0 : (left < per_row ? left : per_row);
+    }
+};
+template <int MF, int NF, int I, bool NEXT, int V>
+__device__ __forceinline__ void sched_row() {
+    if constexpr (I < MF) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NF, 0);
+        if constexpr (NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 1 + TapPlan<MF, NF>::nb(I), 0);
+        constexpr int rows_v = V < MF ? V : MF;  // the last rows_v rows carry the V prefetch loads
+        constexpr int nv = I < MF - rows_v ? 0 : (I == MF - 1 ? V - (rows_v - 1) : 1);
+        if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x020, nv, 0);
+    }
+}
+template <int MF, int NF, bool NEXT, int V>
+__device__ __forceinline__ void sched_tap() {
+    static_assert(MF <= 8, "sched_tap rows");
+    sched_row<MF, NF, 0, NEXT, V>(); sched_row<MF, NF, 1, NEXT, V>(); sched_row<MF, NF, 2, NEXT, V>();
+    sched_row<MF, NF, 3, NEXT, V>(); sched_row<MF, NF, 4, NEXT, V>(); sched_row<MF, NF, 5, NEXT, V>();
+    sched_row<MF, NF, 6, NEXT, V>(); sched_row<MF, NF, 7, NEXT, V>();
+}
+
 // waves_per_eu(2,2): two workgroups per CU, up to 256 registers each - without the cap hipcc spills the
 // prefetched chunk to scratch to reach an occupancy the LDS image would not allow anyway
 template <class T, bool OUT_F32>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv3x3_igemm(const ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))) void k_conv3x3_igemm(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     uint4 *sA = smem;
     uint4 *sB = smem + T::A_SLOTS;
@@ -80,6 +135,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int y0 = ty_i * T::TH, x0 = tx_i * T::TW;
     const int n0 = blockIdx.y * T::BN;
     const int H = a.H, W = a.W, Cin = a.Cin;
+    const int n_chunks = Cin >> 5;
     const uint16_t *xn = a.x + (int64_t)n * H * W * Cin;
 
     // ---- A staging plan: 8 consecutive lanes = 8 consecutive pixels of one k-group (conflict-free
@@ -106,7 +162,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         gy = min(max(gy, 0), H - 1);
         gx = min(max(gx, 0), W - 1);
-        a_goff[it] = (gy * W + gx) * Cin + kg * 8;
+        a_goff[it] = ((gy * W + gx) * Cin + kg * 8) * 2;  // byte offset inside image n
     }
 
     f32x4 acc[T::MF][T::NF];
@@ -125,7 +181,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const int b_base = (lane >> 4) * T::BN + wn * T::WAVE_N + (lane & 15);
 
-    const int n_chunks = Cin >> 5;
     const int c_begin = a.k_splits > 1 ? blockIdx.z * a.chunks_per_split : 0;
     const int c_end = a.k_splits > 1 ? min(c_begin + a.chunks_per_split, n_chunks) : n_chunks;
 
@@ -136,15 +191,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // scratch memory (store-after-load + reload), which serialises the pipeline.
     static_assert(T::A_IT <= 6 && T::B_IT <= 9, "prefetch register file");
     uint4 pa0, pa1, pa2, pa3, pa4, pa5, pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7, pb8;
+    [[maybe_unused]] uint4 pa6, pa7, pa8;  // named by the tap macros, never live (A_IT <= 6)
     pa0 = pa1 = pa2 = pa3 = pa4 = pa5 = pb0 = pb1 = pb2 = pb3 = pb4 = pb5 = pb6 = pb7 = pb8 = make_uint4(0, 0, 0, 0);
-    const uint4 *wbase = reinterpret_cast<const uint4 *>(a.w) + n0;
-#define FOSVOS_LD_A(i) \
-    if constexpr (i < T::A_IT) pa##i = *reinterpret_cast<const uint4 *>(xn + a_goff[i] + cc_ * 32);
+    // buffer loads: one 32-bit byte offset per lane (+ a wave-uniform SGPR offset per chunk / slice) instead of
+    // a 64-bit address per load, and the descriptor's range check covers the weight-slice overrun of the
+    // 16-channel tiles (those lanes are never stored to LDS)
+    // The tap loop prefetches unconditionally; behind the last chunk the descriptors have zero records, so the
+    // range check drops those loads in the texture unit (no branch, no second copy of the MFMA loop).
+    const int x_bytes = H * W * Cin * 2, w_bytes = (n_chunks * 36 * a.Co_pad - n0) * 16;
+    auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(xn), 0, x_bytes, 0x00020000);
+    auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w) + (int64_t)n0 * 8, 0, w_bytes,
+                                                    0x00020000);
+    static_assert(256 % T::BN == 0, "weight staging assumes BN divides the workgroup size");
+    const int b_voff = ((tid / T::BN) * a.Co_pad + tid % T::BN) * 16;
+    const int b_row_bytes = a.Co_pad * 16;
+#define FOSVOS_LD_A(i)                                                                                  \
+    if constexpr (i < T::A_IT)                                                                          \
+        pa##i = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, a_goff[i], cc_ * 64, 0));
 #define FOSVOS_LD_B(i)                                                                                  \
-    if constexpr (i < T::B_IT) {                                                                        \
-        const int idx_ = min(i * 256 + tid, T::B_SLOTS - 1);                                            \
-        pb##i = wbase[((int64_t)cc_ * 36 + idx_ / T::BN) * a.Co_pad + (idx_ % T::BN)];                   \
-    }
+    if constexpr (i < T::B_IT)                                                                          \
+        pb##i = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(                        \
+            w_rsrc, b_voff, (cc_ * 36 + i * (256 / T::BN)) * b_row_bytes, 0));
 #define FOSVOS_LOAD_CHUNK(cc_expr)                                                                      \
     {                                                                                                   \
         const int cc_ = (cc_expr);                                                                      \
@@ -172,46 +239,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         FOSVOS_ST_B(6) FOSVOS_ST_B(7) FOSVOS_ST_B(8)                                                    \
     }
 
-    if (c_begin < c_end) FOSVOS_LOAD_CHUNK(c_begin)
-    for (int cc = c_begin; cc < c_end; ++cc) {
-        if (cc > c_begin) __syncthreads();  // every wave finished reading the previous chunk
-        FOSVOS_STORE_CHUNK()
-        __syncthreads();
-        if (cc + 1 < c_end) FOSVOS_LOAD_CHUNK(cc + 1)
-        // ---- 9 taps x (MF x NF) MFMAs
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
-            bf16x8 af[T::MF], bfr[T::NF];
-#pragma unroll
-            for (int i = 0; i < T::MF; ++i)
-                af[i] = __builtin_bit_cast(bf16x8, sA[a_base[i] + ky * T::HALO_W + kx]);
-#pragma unroll
-            for (int j = 0; j < T::NF; ++j)
-                bfr[j] = __builtin_bit_cast(bf16x8, sB[b_base + tap * 4 * T::BN + j * 16]);
-#pragma unroll
-            for (int i = 0; i < T::MF; ++i)
-#pragma unroll
-                for (int j = 0; j < T::NF; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
+    // Tap loop, software-pipelined by hand (see TapPlan): no LDS round trip and no texture-address stall
+    // (64 B/clk: 15 loads x 8 waves is ~1.7k clocks when issued in one burst) in front of the matrix pipe.
+#define FOSVOS_RD_A(tap_, i_) \
+    af[i_] = __builtin_bit_cast(bf16x8, sA[a_base[i_] + ((tap_) / 3) * T::HALO_W + (tap_) % 3]);
+#define FOSVOS_RD_B(tap_, buf_, j_) \
+    bfr[buf_][j_] = __builtin_bit_cast(bf16x8, sB[b_base + (tap_) * 4 * T::BN + (j_) * 16]);
+#define FOSVOS_ROW(tap_, i_)                                                                            \
+    if constexpr ((i_) < T::MF) {                                                                       \
+        _Pragma("unroll") for (int j = 0; j < T::NF; ++j) acc[i_][j] =                                  \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[(tap_) & 1][j], af[i_], acc[i_][j], 0, 0, 0);   \
+        if constexpr ((tap_) < 8) {                                                                     \
+            FOSVOS_RD_A((tap_) + 1, i_)                                                                 \
+            _Pragma("unroll") for (int j = 0; j < TP::nb(i_); ++j)                                      \
+                FOSVOS_RD_B((tap_) + 1, ((tap_) + 1) & 1, (i_) * TP::per_row + j)                       \
+        }                                                                                               \
+    }
+#define FOSVOS_TAP(tap_)                                                                                \
+    {                                                                                                   \
+        FOSVOS_ROW(tap_, 0) FOSVOS_ROW(tap_, 1) FOSVOS_ROW(tap_, 2) FOSVOS_ROW(tap_, 3)                 \
+        FOSVOS_ROW(tap_, 4) FOSVOS_ROW(tap_, 5) FOSVOS_ROW(tap_, 6) FOSVOS_ROW(tap_, 7)                 \
+        {                                                                                               \
+            const int cc_ = cc + 1;                                                                     \
+            FOSVOS_LD_B(tap_)                                                                           \
+            FOSVOS_LD_A(tap_)                                                                           \
+        }                                                                                               \
+        sched_tap<T::MF, T::NF, ((tap_) < 8), 1 + ((tap_) < T::A_IT ? 1 : 0)>();                        \
     }
 
-    // ---- epilogue.  C/D layout: acc[i][j][r] = out[pixel wm*WAVE_M + 16 i + 4 (lane>>4) + r][channel wn*WAVE_N + 16 j + (lane&15)]
+    FOSVOS_STAMP_RT(11)
+    FOSVOS_STAMP_AT(0)
+    if (c_begin < c_end) FOSVOS_LOAD_CHUNK(c_begin)
+    FOSVOS_STAMP_AT(1)
+    using TP = TapPlan<T::MF, T::NF>;
+    static_assert(T::MF <= 8, "row macros cover up to 8 pixel fragments per wave");
+    bf16x8 af[T::MF], bfr[2][T::NF];
+    for (int cc = c_begin; cc < c_end; ++cc) {
+        if (cc > c_begin) __syncthreads();  // every wave finished reading the previous chunk
+        if (cc == c_end - 1) { FOSVOS_STAMP_AT(6) }
+        FOSVOS_STORE_CHUNK()
+        if (cc == c_begin) { FOSVOS_STAMP_AT(2) }
+        if (cc == c_end - 1) { FOSVOS_STAMP_AT(7) }
+        __syncthreads();
+        if (cc == c_begin) { FOSVOS_STAMP_AT(3) }
+#pragma unroll
+        for (int i = 0; i < T::MF; ++i) FOSVOS_RD_A(0, i)
+#pragma unroll
+        for (int j = 0; j < T::NF; ++j) FOSVOS_RD_B(0, 0, j)
+        __builtin_amdgcn_sched_group_barrier(0x100, T::MF + T::NF, 0);
+        if (cc + 1 == c_end) {  // nothing left to prefetch: zero-record descriptors
+            x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(xn), 0, 0, 0x00020000);
+            w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w) + (int64_t)n0 * 8, 0, 0, 0x00020000);
+        }
+        FOSVOS_TAP(0) FOSVOS_TAP(1) FOSVOS_TAP(2) FOSVOS_TAP(3) FOSVOS_TAP(4) FOSVOS_TAP(5) FOSVOS_TAP(6)
+        FOSVOS_TAP(7) FOSVOS_TAP(8)
+        if (cc == c_begin) { FOSVOS_STAMP_AT(5) }
+    }
+    FOSVOS_STAMP_AT(8)
+
+    // ---- epilogue.  The MFMAs ran with the weight fragment as the row operand, so
+    //   acc[i][j][r] = out[pixel wm*WAVE_M + 16 i + (lane&15)][channel wn*WAVE_N + 16 j + 4 (lane>>4) + r]:
+    // a lane owns 4 consecutive channels of one pixel (one 8-byte bf16 / 16-byte fp32 store).
     const int q = lane >> 4, cl = lane & 15;
     if (a.k_splits > 1) {  // split-K: raw fp32 partial sums, finished by k_splitk_epilogue
         float *po = a.partial + (int64_t)blockIdx.z * a.N * H * W * a.Cout;
 #pragma unroll
-        for (int j = 0; j < T::NF; ++j) {
-            const int co = n0 + wn * T::WAVE_N + j * 16 + cl;
+        for (int i = 0; i < T::MF; ++i) {
+            const int pix = wm * T::WAVE_M + i * 16 + cl;
+            const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
+            if (gy < H && gx < W) {
+                float *row = po + (((int64_t)n * H + gy) * W + gx) * a.Cout + n0 + wn * T::WAVE_N + q * 4;
 #pragma unroll
-            for (int i = 0; i < T::MF; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int pix = wm * T::WAVE_M + i * 16 + q * 4 + r;
-                    const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
-                    if (gy < H && gx < W) po[(((int64_t)n * H + gy) * W + gx) * a.Cout + co] = acc[i][j][r];
-                }
+                for (int j = 0; j < T::NF; ++j)
+                    *reinterpret_cast<float4 *>(row + j * 16) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
         }
         return;
     }
@@ -219,20 +321,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float *yo = reinterpret_cast<float *>(a.y);
 #pragma unroll
         for (int j = 0; j < T::NF; ++j) {
-            const int co = n0 + wn * T::WAVE_N + j * 16 + cl;
-            const float b = a.bias ? a.bias[co] : 0.f;
+            const int co = n0 + wn * T::WAVE_N + j * 16 + q * 4;
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) b = *reinterpret_cast<const float4 *>(a.bias + co);
 #pragma unroll
-            for (int i = 0; i < T::MF; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int pix = wm * T::WAVE_M + i * 16 + q * 4 + r;
-                    const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
-                    if (gy < H && gx < W) {
-                        float v = acc[i][j][r] + b;
-                        if (a.flags & FOSVOS_CONV_RELU) v = fmaxf(v, 0.f);
-                        yo[(((int64_t)n * H + gy) * W + gx) * a.Cout + co] = v;
-                    }
+            for (int i = 0; i < T::MF; ++i) {
+                const int pix = wm * T::WAVE_M + i * 16 + cl;
+                const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
+                if (gy < H && gx < W) {
+                    float4 v = make_float4(acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z,
+                                           acc[i][j][3] + b.w);
+                    if (a.flags & FOSVOS_CONV_RELU)
+                        v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    *reinterpret_cast<float4 *>(yo + (((int64_t)n * H + gy) * W + gx) * a.Cout + co) = v;
                 }
+            }
         }
         return;
     }
@@ -240,19 +343,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     uint16_t *sO = reinterpret_cast<uint16_t *>(smem);
 #pragma unroll
     for (int j = 0; j < T::NF; ++j) {
-        const int col = wn * T::WAVE_N + j * 16 + cl;
-        const float b = a.bias ? a.bias[n0 + col] : 0.f;
+        const int col = wn * T::WAVE_N + j * 16 + q * 4;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) b = *reinterpret_cast<const float4 *>(a.bias + n0 + col);
 #pragma unroll
-        for (int i = 0; i < T::MF; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int pix = wm * T::WAVE_M + i * 16 + q * 4 + r;
-                float v = acc[i][j][r] + b;
-                if (a.flags & FOSVOS_CONV_RELU) v = fmaxf(v, 0.f);
-                sO[pix * T::OUT_LD + col] = f2bf(v);
+        for (int i = 0; i < T::MF; ++i) {
+            const int pix = wm * T::WAVE_M + i * 16 + cl;
+            float v0 = acc[i][j][0] + b.x, v1 = acc[i][j][1] + b.y, v2 = acc[i][j][2] + b.z, v3 = acc[i][j][3] + b.w;
+            if (a.flags & FOSVOS_CONV_RELU) {
+                v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
             }
+            *reinterpret_cast<uint2 *>(sO + pix * T::OUT_LD + col) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+        }
     }
     __syncthreads();
+    FOSVOS_STAMP_AT(9)
     constexpr int VEC_PER_PIX = T::BN / 8;
     uint16_t *yo = reinterpret_cast<uint16_t *>(a.y);
     for (int idx = tid; idx < T::BM * VEC_PER_PIX; idx += 256) {
@@ -280,6 +385,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         *reinterpret_cast<uint4 *>(yo + off) = v;
     }
+    FOSVOS_STAMP_AT(10)
+    FOSVOS_STAMP_RT(12)
 }
 
 // Finish a split-K convolution: out = epilogue(sum_z partial[z] + bias).  One thread = 8 channels of a pixel.
@@ -360,20 +467,30 @@ ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
     auto blocks = [&](int th, int tw, int bn) { return cdiv(W, tw) * cdiv(H, th) * N * (int64_t)(out_ch / bn); };
     int64_t nb;
     if (out_ch % 64 == 0) {
-        if (blocks(8, 32, 64) >= kMinBlocks) { p.tile = kBig; nb = blocks(8, 32, 64); }
-        else if (blocks(8, 16, 64) >= kMinBlocks * 3 / 4) { p.tile = kMid; nb = blocks(8, 16, 64); }
-        else if (pixels >= 4096) { p.tile = kMid; nb = blocks(8, 16, 64); }
+        // 256-pixel tiles as soon as they fill ~80 % of the 512 resident slots in ONE round (measured: 420
+        // workgroups of 8x32 beat 840 of 8x16 by 8 % at 120x214x256); below that the 128-pixel tile, 3 per CU
+        if (blocks(8, 32, 64) >= kMinBlocks * 4 / 5) { p.tile = kBig; nb = blocks(8, 32, 64); }
         else { p.tile = kMid; nb = blocks(8, 16, 64); }
     } else {
         if (pixels >= 256 * 256) { p.tile = kSide; nb = blocks(8, 32, 16); }
         else { p.tile = kSideS; nb = blocks(4, 16, 16); }
     }
+#ifdef FOSVOS_STAMP
+    if (const char *e = getenv("FOSVOS_FORCE_TILE")) {  // lab only
+        p.tile = (TileId)atoi(e);
+        nb = p.tile == kBig ? blocks(8, 32, 64) : p.tile == kMid ? blocks(8, 16, 64) : blocks(4, 16, 64);
+    }
+#endif
     int ks = 1;
     if (nb < kMinBlocks * 3 / 4) {
-        ks = (int)cdiv(kMinBlocks, nb);
+        ks = (int)cdiv(kMinBlocks / 2, nb);  // one workgroup per CU is enough (measured at 30x54x512: 2 splits beat 4)
+        if (ks < 2) ks = 1;
         if (ks > n_chunks) ks = n_chunks;
         if (ks > 16) ks = 16;
     }
+#ifdef FOSVOS_STAMP
+    if (const char *e = getenv("FOSVOS_FORCE_KS")) ks = atoi(e);
+#endif
     p.chunks_per_split = (int)cdiv(n_chunks, ks);
     p.k_splits = (int)cdiv(n_chunks, p.chunks_per_split);
     p.workspace_bytes = p.k_splits > 1 ? (size_t)p.k_splits * pixels * out_ch * sizeof(float) : 0;
@@ -387,6 +504,9 @@ int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st) {
     a.tiles_y = (int)cdiv(a.H, T::TH);
     a.k_splits = plan.k_splits;
     a.chunks_per_split = plan.chunks_per_split;
+#ifdef FOSVOS_STAMP
+    a.stamps = g_stamps;
+#endif
     const int64_t tiles = (int64_t)a.tiles_x * a.tiles_y * a.N;
     FOSVOS_REQUIRE(tiles <= 0x7fffffff && a.Cout % T::BN == 0, FOSVOS_E_SHAPE, "conv3x3: tile grid");
     hipLaunchKernelGGL((k_conv3x3_igemm<T, OUT_F32>),
