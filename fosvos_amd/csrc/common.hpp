@@ -40,14 +40,45 @@ inline int fail(int code, const char *fmt, ...) {
 #define FOSVOS_ENTER(device) FOSVOS_HIP_CHECK(hipSetDevice(device))
 #define FOSVOS_LAUNCH_CHECK() FOSVOS_HIP_CHECK(hipGetLastError())
 
-// internal variants of two exported entry points with an accumulate-into-output flag (used by vgg_net.hip)
+// Weight-gradient reduction queue (conv_wgrad.hip): the MFMA kernel of a layer writes per-split slabs; the fold /
+// final passes that turn them into dw/db can run right away (reduce == nullptr) or be queued here and run for all
+// layers in two launches (wgrad_reduce_all).  A queued layer's workspace must stay untouched until then.
+struct WgradReduceEntry {
+    float *slabs;  // S slabs of 9*Cor*Ci floats, then room for the folded slabs when fold_blocks > 0
+    float *dw, *db;
+    const float *bias_part;
+    int S, S_bias, Co, Cor, Ci, Ci_real, bco, accumulate;
+    int fold_begin, fold_blocks, final_begin, final_blocks;  // block ranges inside the batched launches
+};
+struct WgradReduceTable {
+    int n;
+    WgradReduceEntry e[20];
+};
+int wgrad_impl(const uint16_t *x, const uint16_t *dy, float *dw, float *db, int N, int H, int W, int Ci, int Co,
+               int accumulate, void *workspace, size_t workspace_bytes, int device, void *stream,
+               WgradReduceTable *reduce);
 int first_wgrad_impl(const float *frame, const uint16_t *dy, float *dw, float *db, int N, int H, int W, int Co,
-                     int accumulate, void *workspace, size_t workspace_bytes, int device, void *stream);
-int head_bwd_impl(const float *const side[4], const int hs[4], const int ws[4], const float *const filt[4],
-                  const float *const filt1[4], const float *dsn_w, const float *fuse_w, const float *d_fused,
-                  const float *const d_side_out[4], uint16_t *const d_side[4], float *d_fuse_w, float *d_fuse_b,
-                  float *d_dsn_w, float *d_dsn_b, int N, int H, int W, int accumulate, void *workspace,
-                  size_t workspace_bytes, int device, void *stream);
+                     int accumulate, void *workspace, size_t workspace_bytes, int device, void *stream,
+                     WgradReduceTable *reduce);
+int wgrad_reduce_all(WgradReduceTable *reduce, int device, void *stream);
+// Head backward in pieces, so that vgg_net.hip can put the scales the data-gradient chain does not need yet on the
+// auxiliary stream: check once, then one call per scale (any order, any stream) and the finish pass (after all four).
+struct HeadBwdArgs {
+    const float *const *side;
+    const int *hs, *ws;
+    const float *const *filt, *const *filt1;
+    const float *dsn_w, *fuse_w, *d_fused;
+    const float *const *d_side_out;
+    uint16_t *const *d_side;
+    float *d_fuse_w, *d_fuse_b, *d_dsn_w, *d_dsn_b;
+    int N, H, W, accumulate;
+    void *workspace;
+    size_t workspace_bytes;
+    int device;
+};
+int head_bwd_check(const HeadBwdArgs &a);
+int head_bwd_scale(const HeadBwdArgs &a, int s, void *stream);
+int head_bwd_finish(const HeadBwdArgs &a, void *stream);
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int roundup(int a, int b) { return (a + b - 1) / b * b; }

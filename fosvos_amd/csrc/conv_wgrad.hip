@@ -211,11 +211,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // each summed in increasing s (fixed order).  float4 per thread, grid = (E/1024, kFoldTo).
 constexpr int kFoldTo = 8;
 
-__global__ __launch_bounds__(256) void k_wgrad_fold(const float *__restrict__ slabs, int S, int64_t E,
-                                                     float *__restrict__ folded) {
-    const int64_t i4 = blockIdx.x * 256LL + threadIdx.x;  // float4 index
+__device__ __forceinline__ void fold_body(const float *__restrict__ slabs, int S, int64_t E,
+                                          float *__restrict__ folded, int64_t bx, int y) {
+    const int64_t i4 = bx * 256LL + threadIdx.x;  // float4 index
     if (i4 * 4 >= E) return;
-    const int y = blockIdx.y;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = y; s < S; s += kFoldTo) {
         const float4 v = *reinterpret_cast<const float4 *>(slabs + (int64_t)s * E + i4 * 4);
@@ -224,19 +223,24 @@ __global__ __launch_bounds__(256) void k_wgrad_fold(const float *__restrict__ sl
     *reinterpret_cast<float4 *>(folded + (int64_t)y * E + i4 * 4) = acc;
 }
 
+__global__ __launch_bounds__(256) void k_wgrad_fold(const float *__restrict__ slabs, int S, int64_t E,
+                                                     float *__restrict__ folded) {
+    fold_body(slabs, S, E, folded, blockIdx.x, blockIdx.y);
+}
+
 // stage 2: block = (4 consecutive co = one accumulator float4, 64 consecutive ci): sum the <= kFoldTo slabs
 // (16-byte coalesced reads of the fragment-native layout), transpose through LDS and write 4 runs of 576
 // contiguous floats dw[(co*Ci + ci0)*9 ...] (OIHW).
-__global__ __launch_bounds__(256) void k_wgrad_final(const float *__restrict__ slabs, int S, int Co, int Cor, int Ci,
-                                                      int Ci_real, int bco, int accumulate, float *__restrict__ dw,
-                                                      const float *__restrict__ bias_part, int S_bias,
-                                                      float *__restrict__ db) {
+__device__ __forceinline__ void final_body(const float *__restrict__ slabs, int S, int Co, int Cor, int Ci, int Ci_real,
+                                           int bco, int accumulate, float *__restrict__ dw,
+                                           const float *__restrict__ bias_part, int S_bias, float *__restrict__ db,
+                                           int bx, int by) {
     // Ci = channel count of the slabs (a multiple of 64, or 16 for the padded conv1_1 image); Ci_real = channels
     // of dw (OIHW rows of Ci_real*9 floats)
     __shared__ float tile[4][64 * 9];
     const int cw = Ci < 64 ? Ci : 64;  // ci columns handled by this block
-    const int ci0 = blockIdx.x * 64, co4 = blockIdx.y * 4;
-    if (db && blockIdx.x == 0) {  // the 4 channels' bias: S_bias per-split partials each, fixed-order tree
+    const int ci0 = bx * 64, co4 = by * 4;
+    if (db && bx == 0) {  // the 4 channels' bias: S_bias per-split partials each, fixed-order tree
         __shared__ float redb[256];
         const int r = threadIdx.x >> 6, t = threadIdx.x & 63;
         float acc_b = 0.f;
@@ -276,6 +280,39 @@ __global__ __launch_bounds__(256) void k_wgrad_final(const float *__restrict__ s
         float *d = dw + ((int64_t)(co4 + r) * Ci_real + ci0) * 9 + k;
         *d = accumulate ? *d + tile[r][k] : tile[r][k];
     }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_final(const float *__restrict__ slabs, int S, int Co, int Cor, int Ci,
+                                                      int Ci_real, int bco, int accumulate, float *__restrict__ dw,
+                                                      const float *__restrict__ bias_part, int S_bias,
+                                                      float *__restrict__ db) {
+    final_body(slabs, S, Co, Cor, Ci, Ci_real, bco, accumulate, dw, bias_part, S_bias, db, blockIdx.x, blockIdx.y);
+}
+
+// ---- the same two stages for MANY layers in one launch each (vgg_net.hip queues every layer's slabs and reduces them
+// behind the last MFMA kernel: 2 launches instead of 26 on the weight-gradient stream, and the small layers'
+// reductions run beside the large ones)
+__global__ __launch_bounds__(256) void k_wgrad_fold_all(const WgradReduceTable t) {
+    int e = 0;
+    while (e + 1 < t.n && (int)blockIdx.x >= t.e[e + 1].fold_begin) ++e;
+    const WgradReduceEntry &q = t.e[e];
+    const int local = blockIdx.x - q.fold_begin;
+    if (local >= q.fold_blocks) return;  // entries without a fold stage own no blocks
+    const int64_t E = 9LL * q.Cor * q.Ci;
+    const int bx_count = q.fold_blocks / kFoldTo;
+    fold_body(q.slabs, q.S, E, q.slabs + (int64_t)q.S * E, local % bx_count, local / bx_count);
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_final_all(const WgradReduceTable t) {
+    int e = 0;
+    while (e + 1 < t.n && (int)blockIdx.x >= t.e[e + 1].final_begin) ++e;
+    const WgradReduceEntry &q = t.e[e];
+    const int local = blockIdx.x - q.final_begin;
+    const int64_t E = 9LL * q.Cor * q.Ci;
+    const bool folded = q.fold_blocks > 0;
+    const int nx = q.Ci < 64 ? 1 : q.Ci / 64;
+    final_body(folded ? q.slabs + (int64_t)q.S * E : q.slabs, folded ? kFoldTo : q.S, q.Co, q.Cor, q.Ci, q.Ci_real, q.bco,
+               q.accumulate, q.dw, q.bias_part, q.S_bias, q.db, local % nx, local / nx);
 }
 
 // Workgroups per launch.  Slab traffic = workgroups x block bytes, and the wgrad kernels run on the auxiliary
@@ -319,6 +356,63 @@ extern "C" size_t fosvos_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int 
 extern "C" int fosvos_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, float *dw, float *db, int N, int H, int W,
                                     int Ci, int Co, int accumulate, void *workspace, size_t workspace_bytes, int device,
                                     void *stream) {
+    return fosvos::wgrad_impl(x, dy, dw, db, N, H, W, Ci, Co, accumulate, workspace, workspace_bytes, device, stream,
+                              nullptr);
+}
+
+namespace {
+// Run (reduce == nullptr) or queue the fold / final passes of one layer whose slabs the MFMA kernel just wrote.
+int finish_or_queue(const WgradReduceEntry &q0, WgradReduceTable *reduce, hipStream_t st) {
+    WgradReduceEntry q = q0;
+    const int64_t E = 9LL * q.Cor * q.Ci;
+    const int nx = q.Ci < 64 ? 1 : q.Ci / 64;
+    q.fold_blocks = q.S > kFoldTo ? (int)cdiv(E / 4, 256) * kFoldTo : 0;
+    q.final_blocks = nx * (q.Cor / 4);
+    if (reduce) {
+        FOSVOS_REQUIRE(reduce->n < 20, FOSVOS_E_ARG, "wgrad: reduction queue full");
+        const WgradReduceEntry *prev = reduce->n ? &reduce->e[reduce->n - 1] : nullptr;
+        q.fold_begin = prev ? prev->fold_begin + prev->fold_blocks : 0;
+        q.final_begin = prev ? prev->final_begin + prev->final_blocks : 0;
+        reduce->e[reduce->n++] = q;
+        return FOSVOS_OK;
+    }
+    const float *src = q.slabs;
+    int n_src = q.S;
+    if (q.fold_blocks) {
+        float *folded = q.slabs + (int64_t)q.S * E;
+        hipLaunchKernelGGL(k_wgrad_fold, dim3((unsigned)cdiv(E / 4, 256), kFoldTo), dim3(256), 0, st, q.slabs, q.S, E,
+                           folded);
+        FOSVOS_LAUNCH_CHECK();
+        src = folded;
+        n_src = kFoldTo;
+    }
+    hipLaunchKernelGGL(k_wgrad_final, dim3((unsigned)nx, (unsigned)(q.Cor / 4)), dim3(256), 0, st, src, n_src, q.Co, q.Cor,
+                       q.Ci, q.Ci_real, q.bco, q.accumulate, q.dw, q.bias_part, q.S_bias, q.db);
+    FOSVOS_LAUNCH_CHECK();
+    return FOSVOS_OK;
+}
+}  // namespace
+
+int fosvos::wgrad_reduce_all(WgradReduceTable *reduce, int device, void *stream) {
+    FOSVOS_REQUIRE(reduce, FOSVOS_E_ARG, "wgrad_reduce_all: null table");
+    if (reduce->n == 0) return FOSVOS_OK;
+    FOSVOS_ENTER(device);
+    hipStream_t st = (hipStream_t)stream;
+    const WgradReduceEntry &last = reduce->e[reduce->n - 1];
+    const int fold_total = last.fold_begin + last.fold_blocks, final_total = last.final_begin + last.final_blocks;
+    if (fold_total > 0) {
+        hipLaunchKernelGGL(k_wgrad_fold_all, dim3((unsigned)fold_total), dim3(256), 0, st, *reduce);
+        FOSVOS_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_wgrad_final_all, dim3((unsigned)final_total), dim3(256), 0, st, *reduce);
+    FOSVOS_LAUNCH_CHECK();
+    reduce->n = 0;
+    return FOSVOS_OK;
+}
+
+int fosvos::wgrad_impl(const uint16_t *x, const uint16_t *dy, float *dw, float *db, int N, int H, int W, int Ci, int Co,
+                       int accumulate, void *workspace, size_t workspace_bytes, int device, void *stream,
+                       WgradReduceTable *reduce) {
     FOSVOS_REQUIRE(x && dy && dw && workspace, FOSVOS_E_ARG, "conv3x3_wgrad: null pointer");
     FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, FOSVOS_E_SHAPE, "conv3x3_wgrad: bad shape");
     FOSVOS_REQUIRE(Ci % BCI == 0, FOSVOS_E_SHAPE, "conv3x3_wgrad: Ci=%d must be a multiple of %d", Ci, BCI);
@@ -350,23 +444,10 @@ extern "C" int fosvos_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, float
         hipLaunchKernelGGL(k_wgrad<16>, grid, dim3(256), lds_bytes(1), st, a);
     }
     FOSVOS_LAUNCH_CHECK();
-    {
-        const int64_t E = 9LL * p.Cor * Ci;
-        const float *src = a.slabs;
-        int n_src = p.S;
-        if (p.S > kFoldTo) {
-            float *folded = a.slabs + (int64_t)p.S * E;
-            hipLaunchKernelGGL(k_wgrad_fold, dim3((unsigned)cdiv(E / 4, 256), kFoldTo), dim3(256), 0, st, a.slabs, p.S, E,
-                               folded);
-            FOSVOS_LAUNCH_CHECK();
-            src = folded;
-            n_src = kFoldTo;
-        }
-        hipLaunchKernelGGL(k_wgrad_final, dim3((unsigned)(Ci / 64), (unsigned)(p.Cor / 4)), dim3(256), 0, st, src, n_src, Co,
-                           p.Cor, Ci, Ci, p.bco, accumulate, dw, (const float *)a.bias_part, p.S, db);
-        FOSVOS_LAUNCH_CHECK();
-    }
-    return FOSVOS_OK;
+    WgradReduceEntry q{};
+    q.slabs = a.slabs; q.dw = dw; q.db = db; q.bias_part = a.bias_part;
+    q.S = p.S; q.S_bias = p.S; q.Co = Co; q.Cor = p.Cor; q.Ci = Ci; q.Ci_real = Ci; q.bco = p.bco; q.accumulate = accumulate;
+    return finish_or_queue(q, reduce, st);
 }
 
 // ---------------------------------------------------------------------------------------------- conv1_1
@@ -404,11 +485,12 @@ extern "C" size_t fosvos_conv3x3_first_wgrad_workspace_bytes(int N, int H, int W
 extern "C" int fosvos_conv3x3_first_wgrad(const float *frame, const uint16_t *dy, float *dw, float *db, int N, int H,
                                           int W, int Co, void *workspace, size_t workspace_bytes, int device,
                                           void *stream) {
-    return fosvos::first_wgrad_impl(frame, dy, dw, db, N, H, W, Co, 0, workspace, workspace_bytes, device, stream);
+    return fosvos::first_wgrad_impl(frame, dy, dw, db, N, H, W, Co, 0, workspace, workspace_bytes, device, stream, nullptr);
 }
 
 int fosvos::first_wgrad_impl(const float *frame, const uint16_t *dy, float *dw, float *db, int N, int H, int W, int Co,
-                             int accumulate, void *workspace, size_t workspace_bytes, int device, void *stream) {
+                             int accumulate, void *workspace, size_t workspace_bytes, int device, void *stream,
+                             WgradReduceTable *reduce) {
     FOSVOS_REQUIRE(frame && dy && dw && workspace, FOSVOS_E_ARG, "conv3x3_first_wgrad: null pointer");
     FOSVOS_REQUIRE(Co % 64 == 0, FOSVOS_E_SHAPE, "conv3x3_first_wgrad: Co=%d must be a multiple of 64", Co);
     FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0, FOSVOS_E_SHAPE, "conv3x3_first_wgrad: bad shape N=%d H=%d W=%d", N, H, W);
@@ -429,20 +511,8 @@ int fosvos::first_wgrad_impl(const float *frame, const uint16_t *dy, float *dw, 
     const size_t lds = (size_t)2 * (4 * TPIX + 1 * NPHP) * 32;
     hipLaunchKernelGGL((k_wgrad<64, true>), dim3((unsigned)p.S, 1, (unsigned)(Co / 64)), dim3(256), lds, st, a);
     FOSVOS_LAUNCH_CHECK();
-    const int64_t E = 9LL * Co * 16;
-    const int n_slabs = 4 * p.S;
-    const float *src = a.slabs;
-    int n_src = n_slabs;
-    if (n_slabs > kFoldTo) {
-        float *folded = a.slabs + (int64_t)n_slabs * E;
-        hipLaunchKernelGGL(k_wgrad_fold, dim3((unsigned)cdiv(E / 4, 256), kFoldTo), dim3(256), 0, st, a.slabs, n_slabs, E,
-                           folded);
-        FOSVOS_LAUNCH_CHECK();
-        src = folded;
-        n_src = kFoldTo;
-    }
-    hipLaunchKernelGGL(k_wgrad_final, dim3(1, (unsigned)(Co / 4)), dim3(256), 0, st, src, n_src, Co, Co, 16, 3, 64, accumulate,
-                       dw, (const float *)a.bias_part, p.S, db);
-    FOSVOS_LAUNCH_CHECK();
-    return FOSVOS_OK;
+    WgradReduceEntry q{};
+    q.slabs = a.slabs; q.dw = dw; q.db = db; q.bias_part = a.bias_part;
+    q.S = 4 * p.S; q.S_bias = p.S; q.Co = Co; q.Cor = Co; q.Ci = 16; q.Ci_real = 3; q.bco = 64; q.accumulate = accumulate;
+    return finish_or_queue(q, reduce, st);
 }

@@ -40,72 +40,127 @@ __host__ inline bool make_geom(const int hs[4], const int ws[4], int H, int W, H
 }
 
 // ---------------------------------------------------------------------------------------- forward
-// One thread per output pixel; consecutive lanes = consecutive X, so output stores are coalesced
-// and neighbouring lanes share side-map pixels (served by L1/L2).
+// Workgroup = 16 x 64 output pixels.  Thread (y, xr) owns the 4 pixels x = xr + 16 m of row y: they share their
+// residues modulo every scale's stride (f divides 16), hence the SAME filter taps at every scale, so the
+// 4 taps x 16 channels of filter (pre-multiplied by the fuse weights) are fetched once per scale and thread and
+// reused for the 4 pixels.  The side-map windows of all four scales (at most 10x34, 6x18, 4x10, 3x6 low-res pixels
+// x 16 channels, zero outside the map) are staged in LDS once per workgroup.  The per-pixel formulation read
+// 128 x 16 bytes through the texture path for every output pixel (840 MB per frame: 58 us).
+constexpr int HF_TY = 16, HF_TX = 64;
+__host__ __device__ constexpr int hf_rows(int s) { return HF_TY / (2 << s) + 2; }
+__host__ __device__ constexpr int hf_cols(int s) { return HF_TX / (2 << s) + 2; }
+__host__ __device__ constexpr int hf_off(int s) {  // float offset of scale s's window in LDS
+    int o = 0;
+    for (int i = 0; i < s; ++i) o += hf_rows(i) * hf_cols(i) * 16;
+    return o;
+}
+
 template <bool WITH_SIDE_OUT>
 __global__ __launch_bounds__(256) void k_head_fwd(HeadPtrs p, HeadGeom g, const float *__restrict__ dsn_w,
                                                    const float *__restrict__ dsn_b, const float *__restrict__ fuse_w,
                                                    const float *__restrict__ fuse_b, float *__restrict__ fused,
-                                                   float *so0, float *so1, float *so2, float *so3, int H, int W,
-                                                   int64_t total) {
+                                                   float *so0, float *so1, float *so2, float *so3, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float s_win[hf_off(4)];
     __shared__ float s_fw[64], s_dw[64];
-    if (threadIdx.x < 64) {
-        s_fw[threadIdx.x] = fuse_w[threadIdx.x];
-        s_dw[threadIdx.x] = WITH_SIDE_OUT ? dsn_w[threadIdx.x] : 0.f;
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z, Y0 = blockIdx.y * HF_TY, X0 = blockIdx.x * HF_TX;
+    if (tid < 64) {
+        s_fw[tid] = fuse_w[tid];
+        s_dw[tid] = WITH_SIDE_OUT ? dsn_w[tid] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int f = 2 << s, NR = hf_rows(s), NC = hf_cols(s);
+        const int i_lo = (Y0 + g.top[s]) / f - 1, j_lo = (X0 + g.left[s]) / f - 1;
+        const float4 *sd = reinterpret_cast<const float4 *>(p.side[s] + (int64_t)n * g.hs[s] * g.ws[s] * 16);
+        float4 *dst = reinterpret_cast<float4 *>(s_win + hf_off(s));
+        for (int e = tid; e < NR * NC * 4; e += 256) {
+            const int q = e & 3, px = e >> 2;
+            const int r = px / NC, c = px - r * NC;
+            const int i = i_lo + r, j = j_lo + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i >= 0 && i < g.hs[s] && j >= 0 && j < g.ws[s]) v = sd[((int64_t)i * g.ws[s] + j) * 4 + q];
+            dst[e] = v;
+        }
     }
     __syncthreads();
-    float *so[4] = {so0, so1, so2, so3};
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int X = (int)(idx % W);
-        const int64_t r = idx / W;
-        const int Y = (int)(r % H);
-        const int64_t n = r / H;
-        float out = fuse_b[0];
+    const int y = tid >> 4, xr = tid & 15;
+    const int Y = Y0 + y;
+    const bool row_ok = Y < H;
+    int64_t idx[4];
+    bool px_ok[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int f = 2 << s, k = 4 << s;
-            const int Yo = Y + g.top[s], Xo = X + g.left[s];
-            const int i1 = Yo / f, j1 = Xo / f;
-            const int ky1 = Yo - i1 * f, kx1 = Xo - j1 * f;
-            const float *sd = p.side[s] + n * (int64_t)g.hs[s] * g.ws[s] * 16;
-            const float *fl = p.filt[s];
-            float so_acc = 0.f;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int i = i1 - a, ky = ky1 + a * f;
-                if (i < 0 || i >= g.hs[s]) continue;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int j = j1 - b, kx = kx1 + b * f;
-                    if (j < 0 || j >= g.ws[s]) continue;
-                    const float4 *sp = reinterpret_cast<const float4 *>(sd + ((int64_t)i * g.ws[s] + j) * 16);
-                    float v[16];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 t = sp[q];
-                        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-                    }
-                    const float4 *fp = reinterpret_cast<const float4 *>(fl + (ky * k + kx) * 16);
-                    float fv[16];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 t = fp[q];
-                        fv[4 * q] = t.x; fv[4 * q + 1] = t.y; fv[4 * q + 2] = t.z; fv[4 * q + 3] = t.w;
-                    }
-                    float score = 0.f;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        out += s_fw[16 * s + c] * (fv[c] * v[c]);
-                        if (WITH_SIDE_OUT) score += s_dw[16 * s + c] * v[c];
-                    }
-                    if (WITH_SIDE_OUT) so_acc += (score + dsn_b[s]) * p.filt1[s][ky * k + kx];
-                }
-            }
-            if (WITH_SIDE_OUT) so[s][idx] = so_acc;
-        }
-        fused[idx] = out;
+    for (int m = 0; m < 4; ++m) {
+        const int X = X0 + xr + 16 * m;
+        px_ok[m] = row_ok && X < W;
+        idx[m] = ((int64_t)n * H + Y) * W + X;
     }
+    float out[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) out[m] = fuse_b[0];
+    // the scale and tap loops stay rolled: unrolled, hipcc hoists every filter row of every scale (512 VGPRs + scratch)
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+        const int f = 2 << s, k = 4 << s, NC = HF_TX / f + 2;
+        const int i_lo = (Y0 + g.top[s]) / f - 1, j_lo = (X0 + g.left[s]) / f - 1;
+        const int Yo = Y + g.top[s], Xo = X0 + xr + g.left[s];
+        const int i1 = Yo / f, ky1 = Yo - i1 * f;
+        const int kx1 = Xo % f;  // the same for x + 16 m
+        int woff = 0;
+        for (int t = 0; t < s; ++t) woff += (HF_TY / (2 << t) + 2) * (HF_TX / (2 << t) + 2) * 16;
+        const float *win = s_win + woff;
+        const float *filt = p.filt[s];
+        const float *filt1 = WITH_SIDE_OUT ? p.filt1[s] : nullptr;
+        const float db = WITH_SIDE_OUT ? dsn_b[s] : 0.f;
+        float fw[16], dw[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            fw[c] = s_fw[16 * s + c];
+            dw[c] = s_dw[16 * s + c];
+        }
+        float so_acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int ab = 0; ab < 4; ++ab) {
+            const int a = ab >> 1, b = ab & 1;
+            const int i = i1 - a, ky = ky1 + a * f, kx = kx1 + b * f;
+            float gq[16];  // this tap's filter row, pre-multiplied by the fuse weights of scale s
+            const float4 *fp = reinterpret_cast<const float4 *>(filt + (ky * k + kx) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = fp[q];
+                gq[4 * q] = t.x * fw[4 * q];
+                gq[4 * q + 1] = t.y * fw[4 * q + 1];
+                gq[4 * q + 2] = t.z * fw[4 * q + 2];
+                gq[4 * q + 3] = t.w * fw[4 * q + 3];
+            }
+            const float f1 = WITH_SIDE_OUT ? filt1[ky * k + kx] : 0.f;
+            const bool i_ok = i >= 0 && i < g.hs[s];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int j = (Xo + 16 * m) / f - b;
+                const float4 *vp = reinterpret_cast<const float4 *>(win + ((i - i_lo) * NC + (j - j_lo)) * 16);
+                float dot = 0.f, score = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = vp[q];
+                    dot += gq[4 * q] * v.x + gq[4 * q + 1] * v.y + gq[4 * q + 2] * v.z + gq[4 * q + 3] * v.w;
+                    if (WITH_SIDE_OUT)
+                        score += dw[4 * q] * v.x + dw[4 * q + 1] * v.y + dw[4 * q + 2] * v.z + dw[4 * q + 3] * v.w;
+                }
+                out[m] += dot;
+                if (WITH_SIDE_OUT && i_ok && j >= 0 && j < g.ws[s]) so_acc[m] += (score + db) * f1;
+            }
+        }
+        if (WITH_SIDE_OUT) {
+            float *so = s == 0 ? so0 : s == 1 ? so1 : s == 2 ? so2 : so3;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if (px_ok[m]) so[idx[m]] = so_acc[m];
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (px_ok[m]) fused[idx[m]] = out[m];
 }
 
 // ---------------------------------------------------------------------------------------- backward
@@ -312,16 +367,14 @@ extern "C" int fosvos_head_fwd(const float *const side[4], const int hs[4], cons
                    "head_fwd: side map sizes (%d,%d),(%d,%d),(%d,%d),(%d,%d) do not cover %dx%d", hs[0], ws[0], hs[1],
                    ws[1], hs[2], ws[2], hs[3], ws[3], H, W);
     FOSVOS_ENTER(device);
-    const int64_t total = (int64_t)N * H * W;
-    int64_t blocks = cdiv(total, 256);
-    if (blocks > 65536) blocks = 65536;
+    FOSVOS_REQUIRE(N <= 65535, FOSVOS_E_SHAPE, "head_fwd: batch %d", N);
+    const dim3 grid((unsigned)cdiv(W, HF_TX), (unsigned)cdiv(H, HF_TY), (unsigned)N);
     if (with_so)
-        hipLaunchKernelGGL(k_head_fwd<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, dsn_w, dsn_b,
-                           fuse_w, fuse_b, fused, side_out[0], side_out[1], side_out[2], side_out[3], H, W, total);
+        hipLaunchKernelGGL(k_head_fwd<true>, grid, dim3(256), 0, (hipStream_t)stream, p, g, dsn_w, dsn_b, fuse_w, fuse_b,
+                           fused, side_out[0], side_out[1], side_out[2], side_out[3], H, W);
     else
-        hipLaunchKernelGGL(k_head_fwd<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, dsn_w,
-                           dsn_b, fuse_w, fuse_b, fused, (float *)nullptr, (float *)nullptr, (float *)nullptr,
-                           (float *)nullptr, H, W, total);
+        hipLaunchKernelGGL(k_head_fwd<false>, grid, dim3(256), 0, (hipStream_t)stream, p, g, dsn_w, dsn_b, fuse_w, fuse_b,
+                           fused, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, H, W);
     FOSVOS_LAUNCH_CHECK();
     return FOSVOS_OK;
 }
@@ -354,72 +407,100 @@ extern "C" int fosvos_head_bwd(const float *const side[4], const int hs[4], cons
                                uint16_t *const d_side[4], float *d_fuse_w, float *d_fuse_b, float *d_dsn_w,
                                float *d_dsn_b, int N, int H, int W, void *workspace, size_t workspace_bytes, int device,
                                void *stream) {
-    return fosvos::head_bwd_impl(side, hs, ws, filt, filt1, dsn_w, fuse_w, d_fused, d_side_out, d_side, d_fuse_w, d_fuse_b,
-                                 d_dsn_w, d_dsn_b, N, H, W, 0, workspace, workspace_bytes, device, stream);
+    const HeadBwdArgs a{side, hs, ws, filt, filt1, dsn_w, fuse_w, d_fused, d_side_out, d_side, d_fuse_w, d_fuse_b,
+                        d_dsn_w, d_dsn_b, N, H, W, 0, workspace, workspace_bytes, device};
+    if (int rc = head_bwd_check(a)) return rc;
+    for (int s = 0; s < 4; ++s)
+        if (int rc = head_bwd_scale(a, s, stream)) return rc;
+    return head_bwd_finish(a, stream);
 }
 
-int fosvos::head_bwd_impl(const float *const side[4], const int hs[4], const int ws[4], const float *const filt[4],
-                          const float *const filt1[4], const float *dsn_w, const float *fuse_w, const float *d_fused,
-                          const float *const d_side_out[4], uint16_t *const d_side[4], float *d_fuse_w, float *d_fuse_b,
-                          float *d_dsn_w, float *d_dsn_b, int N, int H, int W, int accumulate, void *workspace,
-                          size_t workspace_bytes, int device, void *stream) {
-    FOSVOS_REQUIRE(side && hs && ws && filt && fuse_w && d_side && d_fuse_w && d_fuse_b && workspace, FOSVOS_E_ARG,
-                   "head_bwd: null pointer");
-    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0, FOSVOS_E_SHAPE, "head_bwd: bad shape N=%d H=%d W=%d", N, H, W);
-    const bool with_so = d_side_out && d_side_out[0];
-    FOSVOS_REQUIRE(d_fused || with_so, FOSVOS_E_ARG, "head_bwd: no upstream gradient given");
+namespace {
+inline bool head_with_so(const HeadBwdArgs &a) { return a.d_side_out && a.d_side_out[0]; }
+}
+
+int fosvos::head_bwd_check(const HeadBwdArgs &a) {
+    FOSVOS_REQUIRE(a.side && a.hs && a.ws && a.filt && a.fuse_w && a.d_side && a.d_fuse_w && a.d_fuse_b && a.workspace,
+                   FOSVOS_E_ARG, "head_bwd: null pointer");
+    FOSVOS_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0, FOSVOS_E_SHAPE, "head_bwd: bad shape N=%d H=%d W=%d", a.N, a.H, a.W);
+    const bool with_so = head_with_so(a);
+    FOSVOS_REQUIRE(a.d_fused || with_so, FOSVOS_E_ARG, "head_bwd: no upstream gradient given");
     HeadGeom g;
-    FOSVOS_REQUIRE(make_geom(hs, ws, H, W, g), FOSVOS_E_SHAPE, "head_bwd: side map sizes do not cover %dx%d", H, W);
+    FOSVOS_REQUIRE(make_geom(a.hs, a.ws, a.H, a.W, g), FOSVOS_E_SHAPE, "head_bwd: side map sizes do not cover %dx%d", a.H,
+                   a.W);
     size_t off[5];
-    const size_t need = head_slab_floats(N, H, W, off) * sizeof(float);
-    FOSVOS_REQUIRE(workspace_bytes >= need, FOSVOS_E_WORKSPACE, "head_bwd: workspace %zu < %zu", workspace_bytes, need);
+    const size_t need = head_slab_floats(a.N, a.H, a.W, off) * sizeof(float);
+    FOSVOS_REQUIRE(a.workspace_bytes >= need, FOSVOS_E_WORKSPACE, "head_bwd: workspace %zu < %zu", a.workspace_bytes, need);
     for (int s = 0; s < 4; ++s) {
-        FOSVOS_REQUIRE(side[s] && filt[s] && d_side[s], FOSVOS_E_ARG, "head_bwd: null pointer at scale %d", s);
-        FOSVOS_REQUIRE(hs[s] <= (((H - 1) >> (s + 1)) + 1) && ws[s] <= (((W - 1) >> (s + 1)) + 1), FOSVOS_E_SHAPE,
+        FOSVOS_REQUIRE(a.side[s] && a.filt[s] && a.d_side[s], FOSVOS_E_ARG, "head_bwd: null pointer at scale %d", s);
+        FOSVOS_REQUIRE(a.hs[s] <= (((a.H - 1) >> (s + 1)) + 1) && a.ws[s] <= (((a.W - 1) >> (s + 1)) + 1), FOSVOS_E_SHAPE,
                        "head_bwd: side map %d larger than the ceil-pooled size", s);
         if (with_so)
-            FOSVOS_REQUIRE(d_side_out[s] && filt1 && filt1[s] && dsn_w && d_dsn_w && d_dsn_b, FOSVOS_E_ARG,
+            FOSVOS_REQUIRE(a.d_side_out[s] && a.filt1 && a.filt1[s] && a.dsn_w && a.d_dsn_w && a.d_dsn_b, FOSVOS_E_ARG,
                            "head_bwd: side-output gradients need all four, filt1, dsn_w, d_dsn_w and d_dsn_b");
     }
-    FOSVOS_ENTER(device);
+    return FOSVOS_OK;
+}
+
+// d_side[s] and the scale's partial sums for the fuse / score_dsn weight gradients (slabs in the workspace)
+int fosvos::head_bwd_scale(const HeadBwdArgs &a, int s, void *stream) {
+    FOSVOS_REQUIRE(s >= 0 && s < 4, FOSVOS_E_ARG, "head_bwd_scale: scale %d", s);
+    const bool with_so = head_with_so(a);
+    HeadGeom g;
+    make_geom(a.hs, a.ws, a.H, a.W, g);
+    size_t off[5];
+    head_slab_floats(a.N, a.H, a.W, off);
+    FOSVOS_ENTER(a.device);
     hipStream_t st = (hipStream_t)stream;
-    float *wsf = reinterpret_cast<float *>(workspace);
+    float *wsf = reinterpret_cast<float *>(a.workspace);
+    const float *f1 = with_so ? a.filt1[s] : nullptr;
+    const float *dw16 = with_so ? a.dsn_w + 16 * s : nullptr;
+    const float *dso = with_so ? a.d_side_out[s] : nullptr;
+#define FOSVOS_HEAD_CASE(SS)                                                                                          \
+    case SS:                                                                                                          \
+        return with_so ? HeadBwdLaunch<SS>::run<true>(a.side[s], a.filt[s], f1, a.fuse_w + 16 * s, dw16, a.d_fused, dso, \
+                                                      a.d_side[s], wsf + off[s], a.N, a.hs[s], a.ws[s], g.top[s],       \
+                                                      g.left[s], a.H, a.W, st)                                         \
+                       : HeadBwdLaunch<SS>::run<false>(a.side[s], a.filt[s], f1, a.fuse_w + 16 * s, dw16, a.d_fused, dso, \
+                                                       a.d_side[s], wsf + off[s], a.N, a.hs[s], a.ws[s], g.top[s],      \
+                                                       g.left[s], a.H, a.W, st);
+    switch (s) {
+        FOSVOS_HEAD_CASE(0)
+        FOSVOS_HEAD_CASE(1)
+        FOSVOS_HEAD_CASE(2)
+        FOSVOS_HEAD_CASE(3)
+    }
+#undef FOSVOS_HEAD_CASE
+    return FOSVOS_OK;
+}
+
+// d_fuse_w, d_fuse_b, d_dsn_w, d_dsn_b from the four scales' slabs (fixed-order sums)
+int fosvos::head_bwd_finish(const HeadBwdArgs &a, void *stream) {
+    const bool with_so = head_with_so(a);
+    size_t off[5];
+    head_slab_floats(a.N, a.H, a.W, off);
+    FOSVOS_ENTER(a.device);
+    hipStream_t st = (hipStream_t)stream;
+    float *wsf = reinterpret_cast<float *>(a.workspace);
     FinishArgs fa;
     for (int s = 0; s < 4; ++s) {
         fa.slabs[s] = wsf + off[s];
-        const float *f1 = with_so ? filt1[s] : nullptr;
-        const float *dw16 = with_so ? dsn_w + 16 * s : nullptr;
-        const float *dso = with_so ? d_side_out[s] : nullptr;
-        int rc = FOSVOS_OK;
-#define FOSVOS_HEAD_CASE(SS)                                                                                          \
-    case SS:                                                                                                          \
-        fa.n_slabs[s] = HeadBwdLaunch<SS>::blocks(N, hs[s], ws[s]);                                                   \
-        rc = with_so ? HeadBwdLaunch<SS>::run<true>(side[s], filt[s], f1, fuse_w + 16 * s, dw16, d_fused, dso, d_side[s], \
-                                                    wsf + off[s], N, hs[s], ws[s], g.top[s], g.left[s], H, W, st)       \
-                     : HeadBwdLaunch<SS>::run<false>(side[s], filt[s], f1, fuse_w + 16 * s, dw16, d_fused, dso,         \
-                                                     d_side[s], wsf + off[s], N, hs[s], ws[s], g.top[s], g.left[s], H, W, \
-                                                     st);                                                             \
-        break;
-        switch (s) {
-            FOSVOS_HEAD_CASE(0)
-            FOSVOS_HEAD_CASE(1)
-            FOSVOS_HEAD_CASE(2)
-            FOSVOS_HEAD_CASE(3)
-        }
-#undef FOSVOS_HEAD_CASE
-        if (rc != FOSVOS_OK) return rc;
+        fa.n_slabs[s] = s == 0 ? HeadBwdLaunch<0>::blocks(a.N, a.hs[s], a.ws[s])
+                      : s == 1 ? HeadBwdLaunch<1>::blocks(a.N, a.hs[s], a.ws[s])
+                      : s == 2 ? HeadBwdLaunch<2>::blocks(a.N, a.hs[s], a.ws[s])
+                               : HeadBwdLaunch<3>::blocks(a.N, a.hs[s], a.ws[s]);
     }
     fa.bias_partials = wsf + off[4];
     fa.n_bias = 0;
-    fa.accumulate = accumulate;
-    if (d_fused) {
+    fa.accumulate = a.accumulate;
+    if (a.d_fused) {
         fa.n_bias = kBiasBlocks;
-        hipLaunchKernelGGL(k_sum_partials, dim3(kBiasBlocks), dim3(256), 0, st, d_fused, (int64_t)N * H * W,
+        hipLaunchKernelGGL(k_sum_partials, dim3(kBiasBlocks), dim3(256), 0, st, a.d_fused, (int64_t)a.N * a.H * a.W,
                            wsf + off[4]);
         FOSVOS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_head_finish, dim3(5), dim3(768), 0, st, fa, d_fuse_w, d_fuse_b, with_so ? d_dsn_w : nullptr,
-                       with_so ? d_dsn_b : nullptr);
+    hipLaunchKernelGGL(k_head_finish, dim3(5), dim3(768), 0, st, fa, a.d_fuse_w, a.d_fuse_b,
+                       with_so ? a.d_dsn_w : nullptr, with_so ? a.d_dsn_b : nullptr);
     FOSVOS_LAUNCH_CHECK();
     return FOSVOS_OK;
 }

@@ -30,8 +30,11 @@ struct Arena {
     size_t gpooled[4];       // gradients wrt them
     size_t side[4];          // fp32 NHWC [N,h,w,16]
     size_t dside[4];         // bf16 NHWC [N,h,w,32]
-    size_t ws, ws_bytes;     // op workspace of the main stream (split-K slabs, head backward)
-    size_t wsa, wsa_bytes;   // op workspace of the wgrad (auxiliary) stream
+    size_t ws, ws_bytes;     // op workspace of the main stream (split-K slabs)
+    size_t hws, hws_bytes;   // head backward slabs (written from both streams, so never shared with `ws`)
+    // per-layer slab workspaces of the wgrad (auxiliary) stream: every layer's slabs stay live until the batched
+    // reduction at the end of the backward pass
+    size_t wsa_conv[kNConv], wsa_conv_bytes[kNConv], wsa_side[4], wsa_side_bytes[4];
     size_t total;
 };
 
@@ -54,29 +57,31 @@ Arena make_arena(int N, int H, int W) {
         a.side[s - 1] = take((size_t)N * a.sh[s] * a.sw[s] * 16 * 4);
         a.dside[s - 1] = take((size_t)N * a.sh[s] * a.sw[s] * 32 * 2);
     }
-    size_t ws = fosvos_head_bwd_workspace_bytes(N, H, W);
-    size_t wsa = fosvos_conv3x3_first_wgrad_workspace_bytes(N, H, W, 64);
+    a.hws_bytes = up256(fosvos_head_bwd_workspace_bytes(N, H, W));
+    a.hws = take(a.hws_bytes);
+    size_t ws = 256;
+    a.wsa_conv_bytes[0] = up256(fosvos_conv3x3_first_wgrad_workspace_bytes(N, H, W, 64));
     for (int c = 1; c < kNConv; ++c) {
         const int s = kStageOf[c];
-        wsa = std::max(wsa, fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kCin[c], kCout[c]));
+        a.wsa_conv_bytes[c] = up256(fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kCin[c], kCout[c]));
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kCin[c], kCout[c]));   // fwd split-K
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kCout[c], kCin[c]));   // dgrad split-K
     }
     for (int s = 1; s < 5; ++s) {
-        wsa = std::max(wsa, fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16));
+        a.wsa_side_bytes[s - 1] = up256(fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16));
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16));
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], 16, kStageCh[s]));
     }
     a.ws_bytes = up256(ws);
     a.ws = take(a.ws_bytes);
-    a.wsa_bytes = up256(wsa);
-    a.wsa = take(a.wsa_bytes);
+    for (int c = 0; c < kNConv; ++c) a.wsa_conv[c] = take(a.wsa_conv_bytes[c]);
+    for (int i = 0; i < 4; ++i) a.wsa_side[i] = take(a.wsa_side_bytes[i]);
     a.total = off;
     return a;
 }
 
 // ---- the library's only persistent state: timing-disabled events for the two-stream backward
-constexpr int kNEvents = 16;  // 13 conv-output gradients + head + fork + join
+constexpr int kNEvents = 19;  // 13 conv-output gradients + head + fork + join + d_side[0..2] (aux -> main)
 struct EventPool {
     hipEvent_t ev[kNEvents];
     bool ready = false;
@@ -168,8 +173,9 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
     auto act = [&](int c) { return reinterpret_cast<uint16_t *>(base + a.act[c]); };
     auto gact = [&](int c) { return reinterpret_cast<uint16_t *>(base + a.gact[c]); };
     void *ws = base + a.ws;
-    void *wsa = base + a.wsa;
     const int acc = g->accumulate ? 1 : 0;
+    WgradReduceTable reduce;  // every layer queues its slab reduction; two launches at the end run them all
+    reduce.n = 0;
 
     // ---- two streams: data-gradient chain on `stream`, weight gradients on `aux_stream`
     hipStream_t sm = (hipStream_t)stream;
@@ -201,11 +207,21 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
         hs[i] = a.sh[i + 1];
         wsz[i] = a.sw[i + 1];
     }
-    FOSVOS_TRY(head_bwd_impl(side, hs, wsz, w->filt, with_so ? w->filt1 : nullptr, with_so ? w->dsn_w : nullptr, w->fuse_w,
-                             d_fused, with_so ? d_side_out : nullptr, dside, g->fuse_w, g->fuse_b,
-                             with_so ? g->dsn_w : nullptr, with_so ? g->dsn_b : nullptr, N, H, W, acc, ws, a.ws_bytes, device,
-                             sm));
-    FOSVOS_TRY(publish(13));  // d_side ready
+    const HeadBwdArgs ha{side, hs, wsz, w->filt, with_so ? w->filt1 : nullptr, with_so ? w->dsn_w : nullptr, w->fuse_w,
+                         d_fused, with_so ? d_side_out : nullptr, dside, g->fuse_w, g->fuse_b,
+                         with_so ? g->dsn_w : nullptr, with_so ? g->dsn_b : nullptr, N, H, W, acc, base + a.hws,
+                         a.hws_bytes, device};
+    FOSVOS_TRY(head_bwd_check(ha));
+    // Only d_side[3] is needed right away (stage 5 runs first): it stays on the data-gradient stream.  The three
+    // larger scales and the fuse / score_dsn weight gradients go to the wgrad stream; the data-gradient stream picks
+    // d_side[s] up (event 16+s) when it reaches side_prep[s].
+    FOSVOS_TRY(head_bwd_scale(ha, 3, sm));
+    for (int i = 2; i >= 0; --i) {
+        FOSVOS_TRY(head_bwd_scale(ha, i, sa));
+        if (par) FOSVOS_HIP_CHECK(hipEventRecord(ev[16 + i], sa));
+    }
+    FOSVOS_TRY(publish(13));  // d_side[3] and its slabs are complete: the finish pass and side_prep[3]'s wgrad may run
+    FOSVOS_TRY(head_bwd_finish(ha, sa));
 
     // ---- stages 4..0
     for (int s = 4; s >= 0; --s) {
@@ -213,23 +229,24 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
         if (s > 0) {
             // side_prep[s-1]: wgrad from (stage output, d_side) on the wgrad stream; its dgrad into the stage-output
             // gradient: ReLU-masked and added to what came back through the next stage's pool (already in gact[last])
-            FOSVOS_TRY(fosvos_conv3x3_wgrad(act(last), dside[s - 1], g->side_w[s - 1], g->side_b[s - 1], N, hh, ww,
-                                            kStageCh[s], 16, acc, wsa, a.wsa_bytes, device, sa));
+            FOSVOS_TRY(wgrad_impl(act(last), dside[s - 1], g->side_w[s - 1], g->side_b[s - 1], N, hh, ww, kStageCh[s], 16,
+                                  acc, base + a.wsa_side[s - 1], a.wsa_side_bytes[s - 1], device, sa, &reduce));
             const uint16_t *addend = (s < 4) ? gact(last) : nullptr;
+            if (par && s < 4) FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[16 + s - 1], 0));  // d_side[s-1] from the wgrad stream
             FOSVOS_TRY(fosvos_conv3x3_dgrad(dside[s - 1], w->side_wd[s - 1], act(last), addend, gact(last), N, hh, ww,
                                             kStageCh[s], 16, ws, a.ws_bytes, device, sm));
         }
         FOSVOS_TRY(publish(last));  // gradient wrt the stage output is complete
         for (int c = last; c >= first; --c) {
             if (c == 0) {
-                FOSVOS_TRY(first_wgrad_impl(frame, gact(0), g->conv_w[0], g->conv_b[0], N, H, W, kCout[0], acc, wsa,
-                                            a.wsa_bytes, device, sa));
+                FOSVOS_TRY(first_wgrad_impl(frame, gact(0), g->conv_w[0], g->conv_b[0], N, H, W, kCout[0], acc,
+                                            base + a.wsa_conv[0], a.wsa_conv_bytes[0], device, sa, &reduce));
                 break;
             }
             const bool from_pool = (c == first) && s > 0;  // its input is the pool output; conv 1 reads conv 0
             const uint16_t *xin = from_pool ? reinterpret_cast<const uint16_t *>(base + a.pooled[s - 1]) : act(c - 1);
-            FOSVOS_TRY(fosvos_conv3x3_wgrad(xin, gact(c), g->conv_w[c], g->conv_b[c], N, hh, ww, kCin[c], kCout[c], acc, wsa,
-                                            a.wsa_bytes, device, sa));
+            FOSVOS_TRY(wgrad_impl(xin, gact(c), g->conv_w[c], g->conv_b[c], N, hh, ww, kCin[c], kCout[c], acc,
+                                  base + a.wsa_conv[c], a.wsa_conv_bytes[c], device, sa, &reduce));
             // dgrad: into the previous conv's output gradient (masked by its ReLU), or into the pool-output gradient
             // (unmasked: the pool backward applies the producer's mask)
             uint16_t *dx = from_pool ? reinterpret_cast<uint16_t *>(base + a.gpooled[s - 1]) : gact(c - 1);
@@ -243,6 +260,7 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
                                                   gact(kLastOfStage[s - 1]), N, a.sh[s - 1], a.sw[s - 1], kStageCh[s - 1], 1,
                                                   device, sm));
     }
+    FOSVOS_TRY(wgrad_reduce_all(&reduce, device, sa));  // slabs -> dw / db for all 17 layers
     if (par && !g->defer_join) {  // join: everything after this call on `stream` sees the weight gradients
         FOSVOS_HIP_CHECK(hipEventRecord(ev[15], sa));
         FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[15], 0));
