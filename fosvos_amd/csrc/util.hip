@@ -154,6 +154,69 @@ __global__ void k_pack_w(const float *__restrict__ w, uint16_t *__restrict__ dst
     }
 }
 
+// Both images of MANY layers in one launch (the step after an optimizer update repacks all 17 layers): a block owns
+// 32 co x 32 ci x 9 taps of one layer, reads its 32 rows of 288 contiguous floats, and writes the two images from LDS
+// in 512-byte runs.  (k_pack_w above gathers 8 floats 36 bytes apart per thread: ~0.5 TB/s.)
+struct PackTable {
+    int n;
+    fosvos_pack_entry e[24];
+    int block_begin[25];
+};
+
+__global__ __launch_bounds__(256) void k_pack_w_tiled(const PackTable t) {
+    __shared__ float tile[32][289];
+    int e = 0;
+    while (e + 1 < t.n && (int)blockIdx.x >= t.block_begin[e + 1]) ++e;
+    const fosvos_pack_entry &q = t.e[e];
+    const int local = blockIdx.x - t.block_begin[e];
+    const int nkb = q.Ci / 32;
+    const int cb = local / nkb, kb = local % nkb;
+    const int co0 = cb * 32, ci0 = kb * 32;
+    for (int i = threadIdx.x; i < 32 * 288; i += 256) {
+        const int r = i / 288, c = i - r * 288;
+        tile[r][c] = (co0 + r < q.Co) ? q.w[((int64_t)(co0 + r) * q.Ci + ci0) * 9 + c] : 0.f;
+    }
+    __syncthreads();
+    const int co_pad = (q.Co + 15) / 16 * 16, ci_pad = (q.Ci + 15) / 16 * 16;
+    for (int g = threadIdx.x; g < 9 * 4 * 32; g += 256) {
+        const int l = g & 31, kc = (g >> 5) & 3, tap = g >> 7;
+        if (q.w_fwd && co0 + l < co_pad) {  // contraction over ci: k-chunk kb, group kc = 8 ci; output channel co0 + l
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = tile[l][(kc * 8 + j) * 9 + tap];
+            *reinterpret_cast<uint4 *>(q.w_fwd + ((((int64_t)kb * 9 + tap) * 4 + kc) * co_pad + co0 + l) * 8) = pack8(f);
+        }
+        if (q.w_dgrad) {  // contraction over co: k-chunk cb, group kc = 8 co; output channel ci0 + l; rotated taps
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = tile[kc * 8 + j][l * 9 + tap];
+            *reinterpret_cast<uint4 *>(q.w_dgrad + ((((int64_t)cb * 9 + (8 - tap)) * 4 + kc) * ci_pad + ci0 + l) * 8) =
+                pack8(f);
+        }
+    }
+}
+
+extern "C" int fosvos_pack_conv3x3_weights_multi(const fosvos_pack_entry *entries, int n, int device, void *stream) {
+    FOSVOS_REQUIRE(entries && n > 0 && n <= 24, FOSVOS_E_ARG, "pack_conv3x3_weights_multi: 1..24 entries, got %d", n);
+    PackTable t;
+    t.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const fosvos_pack_entry &q = entries[i];
+        FOSVOS_REQUIRE(q.w && (q.w_fwd || q.w_dgrad), FOSVOS_E_ARG, "pack_conv3x3_weights_multi: null pointer in entry %d", i);
+        FOSVOS_REQUIRE(q.Co > 0 && q.Ci > 0 && q.Ci % 32 == 0, FOSVOS_E_SHAPE,
+                       "pack_conv3x3_weights_multi: entry %d has Co=%d Ci=%d (Ci must be a multiple of 32)", i, q.Co, q.Ci);
+        t.e[i] = q;
+        t.block_begin[i] = blocks;
+        blocks += (int)cdiv(q.Co, 32) * (q.Ci / 32);
+    }
+    t.block_begin[n] = blocks;
+    FOSVOS_ENTER(device);
+    hipLaunchKernelGGL(k_pack_w_tiled, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
+    FOSVOS_LAUNCH_CHECK();
+    return FOSVOS_OK;
+}
+
 extern "C" size_t fosvos_packed_weight_elems(int out_ch, int in_ch) {
     return (size_t)roundup(in_ch, 32) * 9 * (size_t)roundup(out_ch, 16);
 }

@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 CONV_RELU = 1
 CONV_OUT_F32 = 2
 
@@ -47,6 +47,11 @@ class VggGrads(ctypes.Structure):
                 ("dsn_w", c_void_p), ("dsn_b", c_void_p), ("fuse_w", c_void_p), ("fuse_b", c_void_p),
                 ("accumulate", c_int), ("defer_join", c_int)]
 
+class PackEntry(ctypes.Structure):
+    """fosvos_pack_entry."""
+    _fields_ = [("w", c_void_p), ("w_fwd", c_void_p), ("w_dgrad", c_void_p), ("Co", c_int), ("Ci", c_int)]
+
+
 # name -> (restype, argtypes); every entry point of include/fosvos_hip.h
 SIGNATURES = {
     "fosvos_abi_version": (c_int, []),
@@ -58,6 +63,7 @@ SIGNATURES = {
     "fosvos_nchw_f32_to_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fosvos_pack_conv3x3_weights": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "fosvos_packed_weight_elems": (c_size_t, [c_int, c_int]),
+    "fosvos_pack_conv3x3_weights_multi": (c_int, [POINTER(PackEntry), c_int, c_int, c_void_p]),
     "fosvos_conv3x3_first_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                          c_void_p]),
     "fosvos_conv3x3_first_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -79,6 +79,19 @@ class PackedWeights:
         self._cache[name] = (key, packed)
         return packed
 
+    def conv_many(self, named: Sequence[Tuple[str, torch.Tensor]]):
+        """conv() for a list of layers; all stale images are rebuilt by ONE launch."""
+        stale = []
+        for name, w in named:
+            hit = self._cache.get(name)
+            if hit is None or hit[0] != self._key(w):
+                stale.append((name, w))
+        if stale:
+            packed = ops.pack_conv3x3_weights_multi([w.detach() for _, w in stale])
+            for (name, w), pk in zip(stale, packed):
+                self._cache[name] = (self._key(w), pk)
+        return [self._cache[name][1] for name, _ in named]
+
     def deconv_diag(self, name: str, w: torch.Tensor) -> torch.Tensor:
         """[C,C,k,k] transposed-conv weight -> its diagonal, channel fastest: [k,k,C].  The head kernel applies one
         k x k filter per channel; the reference initialises these layers as diagonal bilinear filters and
@@ -326,14 +339,17 @@ def _weights_struct(P: Dict[str, torch.Tensor], packs: PackedWeights):
     """fosvos_vgg_weights for the current parameter values + the tensors it points into (kept alive by the caller)."""
     w = VggWeights()
     keep = []
+    named = [(wn, P[wn]) for c, (wn, _) in enumerate(_CONV_NAMES) if c > 0]
+    named += [(f"side_prep.{i}.weight", P[f"side_prep.{i}.weight"]) for i in range(4)]
+    images = packs.conv_many(named)  # one launch repacks every layer an optimizer step touched
     for c, (wn, bn) in enumerate(_CONV_NAMES):
         w.conv_w[c] = P[wn].data_ptr()
         w.conv_b[c] = P[bn].data_ptr()
         if c > 0:
-            wf, wd = packs.conv(wn, P[wn])
+            wf, wd = images[c - 1]
             w.conv_wf[c], w.conv_wd[c] = wf.data_ptr(), wd.data_ptr()
     for i in range(4):
-        wf, wd = packs.conv(f"side_prep.{i}.weight", P[f"side_prep.{i}.weight"])
+        wf, wd = images[len(_CONV_NAMES) - 1 + i]
         w.side_wf[i], w.side_wd[i] = wf.data_ptr(), wd.data_ptr()
         w.side_b[i] = P[f"side_prep.{i}.bias"].data_ptr()
         f = packs.deconv_diag(f"upscale.{i}.weight", P[f"upscale.{i}.weight"])

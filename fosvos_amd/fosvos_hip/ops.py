@@ -160,6 +160,32 @@ def pack_conv3x3_weights(w: torch.Tensor, want_fwd: bool = True, want_dgrad: boo
     return fwd, dgr
 
 
+def pack_conv3x3_weights_multi(ws: Sequence[torch.Tensor]):
+    """[(fwd image, dgrad image)] of several fp32 OIHW weights in ONE launch (in channels a multiple of 32)."""
+    from . import PackEntry
+    if not ws:
+        return []
+    L = lib()
+    arr = (PackEntry * len(ws))()
+    out = []
+    nbytes = 0
+    for i, w in enumerate(ws):
+        _need(w, _F32, "pack_conv3x3_weights_multi")
+        co, ci, kh, kw = w.shape
+        if (kh, kw) != (3, 3) or w.device != ws[0].device:
+            raise ValueError("pack_conv3x3_weights_multi: 3x3 kernels on one device only")
+        fwd = torch.empty(L.fosvos_packed_weight_elems(co, ci), dtype=_BF16, device=w.device)
+        dgr = torch.empty(L.fosvos_packed_weight_elems(ci, co), dtype=_BF16, device=w.device)
+        arr[i].w, arr[i].w_fwd, arr[i].w_dgrad, arr[i].Co, arr[i].Ci = w.data_ptr(), fwd.data_ptr(), dgr.data_ptr(), co, ci
+        out.append((fwd, dgr))
+        nbytes += w.numel() * 4 + 2 * (fwd.numel() + dgr.numel())
+    dev, st = _ctx(ws[0])
+    t0 = _pb()
+    check(L.fosvos_pack_conv3x3_weights_multi(arr, len(ws), dev, st), "pack_conv3x3_weights_multi")
+    _pe(t0, "pack_weights", 0.0, nbytes)
+    return out
+
+
 # ------------------------------------------------------------------------------------------ conv
 def conv3x3_first_fwd(frame: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     _need(frame, _F32, "conv3x3_first_fwd frame"); _need(w, _F32, "conv3x3_first_fwd weight"); _need(b, _F32, "conv3x3_first_fwd bias")

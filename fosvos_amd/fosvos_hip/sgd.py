@@ -66,7 +66,8 @@ class FusedSGD(optim.SGD):
                 device = p.device
                 entries.append((p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel(), float(group["lr"]),
                                 float(group["weight_decay"])))
-                updated.append(p)
+                if float(group["lr"]) != 0.0:  # lr 0 (the frozen upscale filters): the value cannot change
+                    updated.append(p)
                 max_numel = max(max_numel, p.numel())
         if not entries:
             return loss

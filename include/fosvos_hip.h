@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 4
+#define FOSVOS_ABI_VERSION 5
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -74,6 +74,16 @@ int fosvos_nchw_f32_to_nhwc_f32(const float *src, float *dst, int N, int C, int 
 int fosvos_pack_conv3x3_weights(const float *w_oihw, int Co, int Ci, uint16_t *w_fwd, uint16_t *w_dgrad,
                                 int device, void *stream);
 size_t fosvos_packed_weight_elems(int out_ch, int in_ch); /* elements of one packed image */
+
+/* Both images of several layers in ONE launch (what the shipped module does after every optimizer step; replaces
+ * 2 launches per layer).  Entry i packs w [Co,Ci,3,3] into w_fwd and/or w_dgrad (either may be NULL); Ci % 32 == 0.
+ * `entries` is host memory, read before the call returns. */
+typedef struct fosvos_pack_entry {
+    const float *w;
+    uint16_t *w_fwd, *w_dgrad;
+    int Co, Ci;
+} fosvos_pack_entry;
+int fosvos_pack_conv3x3_weights_multi(const fosvos_pack_entry *entries, int n, int device, void *stream);
 
 /* ---- first layer: conv1_1 (Ci = 3) straight from the fp32 NCHW frame --------------------------
  * y[N,H,W,Co] bf16 = relu(conv3x3(frame, w, pad 1) + b), fp32 VALU arithmetic (K = 27).

@@ -95,6 +95,18 @@ def test_pack_weights(ops, co, ci):
     assert torch.equal(dgr.float().cpu(), bf(_pack_ref(w, True)))
 
 
+def test_pack_weights_multi(ops):
+    """One launch for many layers (what the module does after an optimizer step) == the per-layer packer, bit for bit;
+    covers a 16-channel side layer (half-empty 32-channel block) and non-square layers."""
+    shapes = [(64, 64), (128, 64), (16, 128), (256, 128), (16, 512), (96, 32)]
+    ws = [gen(co, ci, 3, 3, seed=40 + i) for i, (co, ci) in enumerate(shapes)]
+    got = ops.pack_conv3x3_weights_multi([w.to(DEV) for w in ws])
+    assert len(got) == len(ws)
+    for w, (fwd, dgr) in zip(ws, got):
+        assert torch.equal(fwd.float().cpu(), bf(_pack_ref(w, False)))
+        assert torch.equal(dgr.float().cpu(), bf(_pack_ref(w, True)))
+
+
 # ------------------------------------------------------------------------------------------ conv1_1
 @pytest.mark.parametrize("n,h,w", [(1, 48, 86), (2, 61, 107), (1, 5, 3), (1, 4, 64), (1, 9, 130)])
 def test_conv_first_fwd(ops, n, h, w):
