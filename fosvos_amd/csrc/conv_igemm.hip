@@ -30,6 +30,7 @@ struct ConvArgs {
     const uint16_t *relu_src;  // [N,H,W,Cout] or null
     const uint16_t *addend;    // [N,H,W,Cout] or null
     void *y;                   // [N,H,W,Cout] bf16 (or fp32)
+    uint16_t *y_pool;          // optional [N,ceil(H/2),ceil(W/2),Cout] bf16: 2x2 ceil-mode max pool of y, same launch
     int N, H, W, Cin, Cout, Co_pad;
     int tiles_x, tiles_y;
     unsigned flags;
@@ -385,6 +386,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))
         }
         *reinterpret_cast<uint4 *>(yo + off) = v;
     }
+    if (a.y_pool) {
+        // fused MaxPool2d(2,2,ceil_mode=True) of this tile (tile origins and sizes are even, so no pooling window
+        // straddles two tiles): the next stage's input is written from the staged tile instead of re-reading y
+        static_assert(T::TH % 2 == 0 && T::TW % 2 == 0, "pooling windows must not straddle tiles");
+        constexpr int PW = T::TW / 2, PN = (T::TH / 2) * PW;
+        const int OH = (H + 1) >> 1, OW = (W + 1) >> 1;
+        for (int idx = tid; idx < PN * VEC_PER_PIX; idx += 256) {
+            const int pp = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
+            const int py = pp / PW, px = pp % PW;
+            const int oy = (y0 >> 1) + py, ox = (x0 >> 1) + px;
+            if (oy >= OH || ox >= OW) continue;
+            float m[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ly = 2 * py + (t >> 1), lx = 2 * px + (t & 1);
+                if (y0 + ly < H && x0 + lx < W) {
+                    float f[8];
+                    unpack8(*reinterpret_cast<const uint4 *>(sO + (ly * T::TW + lx) * T::OUT_LD + cg * 8), f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m[j] = f[j] > m[j] ? f[j] : m[j];
+                }
+            }
+            *reinterpret_cast<uint4 *>(a.y_pool + (((int64_t)n * OH + oy) * OW + ox) * a.Cout + n0 + cg * 8) = pack8(m);
+        }
+    }
     FOSVOS_STAMP_AT(10)
     FOSVOS_STAMP_RT(12)
 }
@@ -574,6 +602,25 @@ extern "C" int fosvos_conv3x3_fwd(const uint16_t *x, const uint16_t *w_packed, c
     FOSVOS_ENTER(device);
     ConvArgs a{};
     a.x = x; a.w = w_packed; a.bias = bias; a.relu_src = nullptr; a.addend = nullptr; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = roundup(Ci, 32); a.Cout = Co; a.Co_pad = roundup(Co, 16); a.flags = flags;
+    return dispatch(a, Ci, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int fosvos_conv3x3_fwd_pool(const uint16_t *x, const uint16_t *w_packed, const float *bias, uint16_t *y,
+                                       uint16_t *y_pool, int N, int H, int W, int Ci, int Co, unsigned flags,
+                                       void *workspace, size_t workspace_bytes, int device, void *stream) {
+    if (int rc = check_common(x, w_packed, y, N, H, W, Ci, Co, "conv3x3_fwd_pool")) return rc;
+    FOSVOS_REQUIRE(y_pool, FOSVOS_E_ARG, "conv3x3_fwd_pool: null pooled output");
+    FOSVOS_REQUIRE((flags & ~FOSVOS_CONV_RELU) == 0, FOSVOS_E_ARG, "conv3x3_fwd_pool: unknown flags 0x%x", flags);
+    FOSVOS_REQUIRE(Co % 64 == 0, FOSVOS_E_SHAPE, "conv3x3_fwd_pool: Co=%d must be a multiple of 64", Co);
+    if (make_plan(N, H, W, Ci, Co).k_splits > 1) {  // small maps (split-K): the epilogue kernel has no tile to pool
+        if (int rc = fosvos_conv3x3_fwd(x, w_packed, bias, y, N, H, W, Ci, Co, flags, workspace, workspace_bytes, device, stream))
+            return rc;
+        return fosvos_maxpool2x2_ceil_fwd(y, y_pool, N, H, W, Co, device, stream);
+    }
+    FOSVOS_ENTER(device);
+    ConvArgs a{};
+    a.x = x; a.w = w_packed; a.bias = bias; a.relu_src = nullptr; a.addend = nullptr; a.y = y; a.y_pool = y_pool;
     a.N = N; a.H = H; a.W = W; a.Cin = roundup(Ci, 32); a.Cout = Co; a.Co_pad = roundup(Co, 16); a.flags = flags;
     return dispatch(a, Ci, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -137,13 +137,16 @@ extern "C" int fosvos_vgg_forward(const fosvos_vgg_weights *w, const float *fram
         if (c == 0) {
             FOSVOS_TRY(fosvos_conv3x3_first_fwd(frame, w->conv_w[0], w->conv_b[0], act(0), N, H, W, kCout[0], device, stream));
         } else {
-            if (c == kFirstOfStage[s]) {  // stage entry: 2x2 ceil max pool of the previous stage's output
-                uint16_t *p = reinterpret_cast<uint16_t *>(base + a.pooled[s - 1]);
-                FOSVOS_TRY(fosvos_maxpool2x2_ceil_fwd(x, p, N, a.sh[s - 1], a.sw[s - 1], kStageCh[s - 1], device, stream));
-                x = p;
+            if (c == kFirstOfStage[s])  // stage entry: the pooled map the previous stage's last conv wrote
+                x = reinterpret_cast<uint16_t *>(base + a.pooled[s - 1]);
+            if (c == kLastOfStage[s] && s < 4) {  // the pool that feeds the next stage rides in this conv's epilogue
+                FOSVOS_TRY(fosvos_conv3x3_fwd_pool(x, w->conv_wf[c], w->conv_b[c], act(c),
+                                                   reinterpret_cast<uint16_t *>(base + a.pooled[s]), N, a.sh[s], a.sw[s],
+                                                   kCin[c], kCout[c], FOSVOS_CONV_RELU, ws, a.ws_bytes, device, stream));
+            } else {
+                FOSVOS_TRY(fosvos_conv3x3_fwd(x, w->conv_wf[c], w->conv_b[c], act(c), N, a.sh[s], a.sw[s], kCin[c], kCout[c],
+                                              FOSVOS_CONV_RELU, ws, a.ws_bytes, device, stream));
             }
-            FOSVOS_TRY(fosvos_conv3x3_fwd(x, w->conv_wf[c], w->conv_b[c], act(c), N, a.sh[s], a.sw[s], kCin[c], kCout[c],
-                                          FOSVOS_CONV_RELU, ws, a.ws_bytes, device, stream));
         }
         x = act(c);
         if (s > 0 && c == kLastOfStage[s])

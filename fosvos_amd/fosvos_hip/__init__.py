@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 CONV_RELU = 1
 CONV_OUT_F32 = 2
 
@@ -71,6 +71,8 @@ SIGNATURES = {
     "fosvos_conv3x3_first_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "fosvos_conv3x3_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_uint,
                                    c_void_p, c_size_t, c_int, c_void_p]),
+    "fosvos_conv3x3_fwd_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_int, c_uint, c_void_p, c_size_t, c_int, c_void_p]),
     "fosvos_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "fosvos_conv3x3_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                      c_int, c_void_p, c_size_t, c_int, c_void_p]),

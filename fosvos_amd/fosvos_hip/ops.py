@@ -245,6 +245,29 @@ def conv3x3_fwd(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Te
     return y
 
 
+def conv3x3_fwd_pool(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], ci: int, co: int,
+                     relu: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """conv3x3_fwd (bf16 output) and the 2x2 ceil-mode max pool of its output from one launch: (y, pooled y)."""
+    _need(x, _BF16, "conv3x3_fwd_pool x"); _need(w_packed, _BF16, "conv3x3_fwd_pool packed weight")
+    n, h, wd, cx = x.shape
+    if cx != _ru(ci, 32):
+        raise ValueError(f"conv3x3_fwd_pool: x has {cx} channels, expected {_ru(ci, 32)}")
+    L = lib()
+    if w_packed.numel() != L.fosvos_packed_weight_elems(co, ci):
+        raise ValueError("conv3x3_fwd_pool: packed weight size does not match (Co, Ci)")
+    if bias is not None:
+        _need(bias, _F32, "conv3x3_fwd_pool bias")
+    y = torch.empty((n, h, wd, co), dtype=_BF16, device=x.device)
+    yp = torch.empty((n, (h + 1) // 2, (wd + 1) // 2, co), dtype=_BF16, device=x.device)
+    ws, wsn = _WS.get(L.fosvos_conv3x3_workspace_bytes(n, h, wd, ci, co), x.device)
+    dev, st = _ctx(x)
+    t0 = _pb()
+    check(L.fosvos_conv3x3_fwd_pool(x.data_ptr(), w_packed.data_ptr(), _p(bias), y.data_ptr(), yp.data_ptr(), n, h, wd, ci,
+                                    co, CONV_RELU if relu else 0, ws, wsn, dev, st), "conv3x3_fwd_pool")
+    _pe(t0, "conv3x3_fwd", 2.0 * n * h * wd * 9 * ci * co, n * h * wd * (2 * cx + 2 * co) + 2 * 9 * ci * co + yp.numel() * 2)
+    return y, yp
+
+
 def conv3x3_dgrad(dy: torch.Tensor, w_dgrad_packed: torch.Tensor, ci: int, co: int,
                   relu_src: Optional[torch.Tensor] = None, addend: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:

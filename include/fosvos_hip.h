@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 5
+#define FOSVOS_ABI_VERSION 6
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -107,6 +107,13 @@ size_t fosvos_conv3x3_first_wgrad_workspace_bytes(int N, int H, int W, int Co);
 int fosvos_conv3x3_fwd(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int N, int H, int W,
                        int Ci, int Co, unsigned flags, void *workspace, size_t workspace_bytes, int device,
                        void *stream);
+
+/* fosvos_conv3x3_fwd plus MaxPool2d(2,2,ceil_mode=True) of its output in the same launch (the last conv of a VGG stage
+ * feeds both the side branch and the pool, src/networks/osvos_vgg.py:90-93): y as above (bf16, Co % 64 == 0),
+ * y_pool = [N, ceil(H/2), ceil(W/2), Co] bf16.  Saves the pool kernel's re-read of y. */
+int fosvos_conv3x3_fwd_pool(const uint16_t *x, const uint16_t *w_packed, const float *bias, uint16_t *y,
+                            uint16_t *y_pool, int N, int H, int W, int Ci, int Co, unsigned flags, void *workspace,
+                            size_t workspace_bytes, int device, void *stream);
 /* Scratch for fwd/dgrad with `in_ch` contraction and `out_ch` output channels (split-K partial
  * slabs for layers whose pixel count alone cannot fill 256 CUs; 0 when none is needed). */
 size_t fosvos_conv3x3_workspace_bytes(int N, int H, int W, int in_ch, int out_ch);

@@ -166,6 +166,23 @@ def test_conv3x3_fwd(ops, n, h, w, ci, co):
     assert_bf16_close(from_nhwc(y2), ref2, "conv3x3_fwd linear")
 
 
+@pytest.mark.parametrize("n,h,w,ci,co", [(1, 48, 86, 64, 64), (1, 61, 107, 64, 128), (2, 33, 47, 128, 128),
+                                          (1, 15, 27, 256, 512), (1, 7, 5, 64, 64), (1, 120, 214, 64, 64)])
+def test_conv3x3_fwd_pool(ops, n, h, w, ci, co):
+    """Last conv of a stage with the ceil-mode pool fused into its epilogue: y identical to the plain conv, pooled map
+    identical to the pool kernel on y (odd sizes: ragged last row/column windows; small maps: the split-K fallback)."""
+    x = bf(gen(n, ci, h, w, seed=50))
+    wt = gen(co, ci, 3, 3, seed=51, scale=math.sqrt(2.0 / (9 * ci)))
+    b = gen(co, seed=52, scale=0.2)
+    wf, _ = ops.pack_conv3x3_weights(wt.to(DEV))
+    y_ref = ops.conv3x3_fwd(to_nhwc_bf16(x), wf, b.to(DEV), ci, co, relu=True)
+    y, yp = ops.conv3x3_fwd_pool(to_nhwc_bf16(x), wf, b.to(DEV), ci, co, relu=True)
+    assert torch.equal(y, y_ref)
+    assert yp.shape == (n, (h + 1) // 2, (w + 1) // 2, co)
+    assert torch.equal(yp, ops.maxpool_fwd(y_ref))
+    assert torch.equal(from_nhwc(yp), F.max_pool2d(from_nhwc(y_ref), 2, 2, ceil_mode=True))
+
+
 @pytest.mark.parametrize("n,h,w,ci", [(1, 120, 214, 128), (1, 30, 54, 512), (2, 15, 27, 256), (1, 3, 2, 128),
                                        (1, 300, 300, 128)])
 def test_conv3x3_side_prep_f32(ops, n, h, w, ci):
