@@ -96,7 +96,6 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     time_all_start = timeit.default_timer()
     n_iters = 0
     for epoch in range(start_epoch, n_epochs):
-        loss_epoch = torch.zeros((), device=device)
         for minibatch_index, minibatch in enumerate(dataloader):
             inputs, gts = minibatch['image'], minibatch['gt']
             inputs, gts = gpu_handler.cast_cuda_if_possible([inputs, gts])
@@ -116,7 +115,8 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
 
             loss = loss / avg_grad_every_n
             loss.backward()
-            loss_epoch += loss.detach()
+            # (the reference also sums loss.item() into a per-epoch tensorboard scalar, src/train_online.py:94-104: one
+            # device sync per frame; running_loss_tr above carries the same information without it)
             counter_gradient += 1
             n_iters += 1
 
