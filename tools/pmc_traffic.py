@@ -15,7 +15,7 @@ fdir, wdir, out, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 
 
 def load(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"))[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
