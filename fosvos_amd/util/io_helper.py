@@ -1,6 +1,6 @@
 """Host plumbing around the loops (reference: src/util/io_helper.py): DataLoader factories, an
-optional tensorboard writer and the YAML settings dump.  DAVIS itself is a "next" row;
-``synthetic=(H, W)`` selects the synthetic sequence."""
+optional tensorboard writer and the YAML settings dump.  ``synthetic=(H, W)`` selects the synthetic sequence
+instead of a DAVIS tree on disk."""
 import dataclasses
 from pathlib import Path
 from typing import Optional, Tuple
@@ -8,6 +8,8 @@ from typing import Optional, Tuple
 import yaml
 from torch.utils.data import DataLoader
 
+from dataloaders import custom_transforms
+from dataloaders.davis_2016 import DAVIS2016
 from dataloaders.synthetic import SyntheticSequence
 from util.logger import get_logger
 
@@ -42,20 +44,16 @@ def write_settings(save_dir: Path, name: str, settings, variant_offline: Optiona
         yaml.safe_dump(dataclasses.asdict(settings), f, default_flow_style=False)
 
 
-def _davis(train: bool, db_root_dir, seq_name):
-    try:
-        from dataloaders.davis_2016 import DAVIS2016  # not built yet
-    except ImportError as e:
-        raise RuntimeError("the DAVIS2016 loader is not part of this build yet; run with --synthetic") from e
-    return DAVIS2016(train=train, db_root_dir=db_root_dir, seq_name=seq_name)
-
-
 def get_data_loader_train(db_root_dir, batch_size: int, seq_name: Optional[str] = None,
                           synthetic: Optional[Tuple[int, int]] = None) -> DataLoader:
     if synthetic is not None:
         ds = SyntheticSequence(seq_name or 'synthetic', synthetic[0], synthetic[1], n_frames=1)
         return DataLoader(ds, batch_size=batch_size, shuffle=True, num_workers=0)
-    return DataLoader(_davis(True, db_root_dir, seq_name), batch_size=batch_size, shuffle=True, num_workers=1)
+    # src/util/io_helper.py:62-70: random flip, random rescale (ScaleNRotate stays disabled as in the reference), ToTensor
+    composed = custom_transforms.Compose([custom_transforms.RandomHorizontalFlip(), custom_transforms.Resize(),
+                                          custom_transforms.ToTensor()])
+    db_train = DAVIS2016(mode='train', db_root_dir=str(db_root_dir), transform=composed, seq_name=seq_name)
+    return DataLoader(db_train, batch_size=batch_size, shuffle=True, num_workers=1)
 
 
 def get_data_loader_test(db_root_dir, batch_size: int, seq_name: Optional[str] = None,
@@ -63,4 +61,6 @@ def get_data_loader_test(db_root_dir, batch_size: int, seq_name: Optional[str] =
     if synthetic is not None:
         ds = SyntheticSequence(seq_name or 'synthetic', synthetic[0], synthetic[1], n_frames=n_frames)
         return DataLoader(ds, batch_size=batch_size, shuffle=False, num_workers=0)
-    return DataLoader(_davis(False, db_root_dir, seq_name), batch_size=batch_size, shuffle=False, num_workers=2)
+    db_test = DAVIS2016(mode='test', db_root_dir=str(db_root_dir), transform=custom_transforms.ToTensor(),
+                        seq_name=seq_name)
+    return DataLoader(db_test, batch_size=batch_size, shuffle=False, num_workers=2)

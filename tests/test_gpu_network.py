@@ -316,3 +316,44 @@ def test_train_online_entry_point(tmp_path, monkeypatch):
     train_online.train_and_test(prov, "synthetic", settings)
     assert (tmp_path / "out" / "vgg16_synthetic_epoch-9.pth").exists()
     assert len(list((tmp_path / "results" / "vgg16" / "online" / "synthetic").glob("*.png"))) == 4
+
+
+def test_train_online_on_a_davis_tree(tmp_path, monkeypatch):
+    """the same entry point fed by the DAVIS2016 loader (frames and masks on disk, random flip /
+    rescale augmentation, so the frame size changes between steps) instead of the synthetic sequence."""
+    from PIL import Image
+    monkeypatch.chdir(tmp_path)
+    import train_online
+    from networks.osvos_vgg import OSVOS_VGG
+    from util.network_provider import provider_mapping
+    from util.settings import OnlineSettings
+    root = tmp_path / "DAVIS"
+    (root / "JPEGImages" / "480p" / "blob").mkdir(parents=True)
+    (root / "Annotations" / "480p" / "blob").mkdir(parents=True)
+    (root / "ImageSets" / "480p").mkdir(parents=True)
+    rng = np.random.RandomState(5)
+    lines = []
+    for k in range(3):
+        yy, xx = np.mgrid[0:80, 0:120]
+        m = (((yy - 40) / 22.0) ** 2 + ((xx - 55 - 4 * k) / 30.0) ** 2 <= 1.0)
+        frame = (rng.randint(0, 120, size=(80, 120, 3)) + 110 * m[:, :, None]).astype(np.uint8)
+        Image.fromarray(frame).save(str(root / "JPEGImages" / "480p" / "blob" / ("%05d.jpg" % k)), quality=95)
+        Image.fromarray((m * 255).astype(np.uint8)).save(str(root / "Annotations" / "480p" / "blob" / ("%05d.png" % k)))
+        lines.append("/JPEGImages/480p/blob/%05d.jpg /Annotations/480p/blob/%05d.png\n" % (k, k))
+    for split in ("train", "val", "trainval"):
+        (root / "ImageSets" / "480p" / (split + ".txt")).write_text("".join(lines))
+    torch.manual_seed(0)
+    parent = tmp_path / "parent.pth"
+    torch.save(OSVOS_VGG(pretrained=0).state_dict(), str(parent))
+    train_online.synthetic_size = None
+    train_online.db_root_dir = root
+    settings = OnlineSettings(is_training=True, is_testing=True, start_epoch=0, n_epochs=6, avg_grad_every_n=2,
+                              snapshot_every_n=6, is_testing_while_training=False, test_every_n=5, batch_size_train=1,
+                              batch_size_test=1, is_visualizing_network=False, is_visualizing_results=False,
+                              variant_offline=None, eval_speeds=False, offline_epoch=240, variant_online=None)
+    prov = provider_mapping[("online", "vgg16")](name="vgg16", save_dir=(parent, tmp_path / "out"), settings=settings)
+    train_online.train_and_test(prov, "blob", settings)
+    assert (tmp_path / "out" / "vgg16_blob_epoch-5.pth").exists()
+    pngs = sorted((tmp_path / "results" / "vgg16" / "online" / "blob").glob("*.png"))
+    assert [p.name for p in pngs] == ["00000.png", "00001.png", "00002.png"]
+    assert np.asarray(Image.open(str(pngs[0]))).shape[:2] == (80, 120)
