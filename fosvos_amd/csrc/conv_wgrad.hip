@@ -393,6 +393,40 @@ int finish_or_queue(const WgradReduceEntry &q0, WgradReduceTable *reduce, hipStr
 }
 }  // namespace
 
+namespace {
+WgradReduceEntry make_entry(const Plan &p, void *workspace, float *dw, float *db, int Ci, int Co, int accumulate) {
+    WgradReduceEntry q{};
+    q.slabs = reinterpret_cast<float *>(workspace);
+    q.dw = dw;
+    q.db = db;
+    q.bias_part = db ? reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + p.slab_bytes) : nullptr;
+    q.S = p.S; q.S_bias = p.S; q.Co = Co; q.Cor = p.Cor; q.Ci = Ci; q.Ci_real = Ci; q.bco = p.bco; q.accumulate = accumulate;
+    return q;
+}
+}  // namespace
+
+extern "C" int fosvos_conv3x3_wgrad_reduce(float *dw, float *db, int N, int H, int W, int Ci, int Co, int accumulate,
+                                           void *workspace, size_t workspace_bytes, int device, void *stream) {
+    FOSVOS_REQUIRE(dw && workspace, FOSVOS_E_ARG, "conv3x3_wgrad_reduce: null pointer");
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && Ci % BCI == 0 && (Co % 64 == 0 || Co == 16), FOSVOS_E_SHAPE,
+                   "conv3x3_wgrad_reduce: bad shape");
+    const Plan p = make_plan(N, H, W, Ci, Co);
+    FOSVOS_REQUIRE(workspace_bytes >= p.slab_bytes + p.bias_bytes, FOSVOS_E_WORKSPACE,
+                   "conv3x3_wgrad_reduce: workspace %zu < %zu", workspace_bytes, p.slab_bytes + p.bias_bytes);
+    FOSVOS_ENTER(device);
+    return finish_or_queue(make_entry(p, workspace, dw, db, Ci, Co, accumulate), nullptr, (hipStream_t)stream);
+}
+
+extern "C" int fosvos_conv3x3_wgrad_slabs(const uint16_t *x, const uint16_t *dy, int with_bias, int N, int H, int W, int Ci,
+                                          int Co, void *workspace, size_t workspace_bytes, int device, void *stream) {
+    // the queue form of wgrad_impl with a throw-away queue: the MFMA kernel runs, the reduction is left to the caller
+    WgradReduceTable sink;
+    sink.n = 0;
+    float dummy = 0.f;  // never dereferenced on the host; only "non-null" matters for the bias partials
+    return fosvos::wgrad_impl(x, dy, &dummy, with_bias ? &dummy : nullptr, N, H, W, Ci, Co, 0, workspace, workspace_bytes,
+                              device, stream, &sink);
+}
+
 int fosvos::wgrad_reduce_all(WgradReduceTable *reduce, int device, void *stream) {
     FOSVOS_REQUIRE(reduce, FOSVOS_E_ARG, "wgrad_reduce_all: null table");
     if (reduce->n == 0) return FOSVOS_OK;

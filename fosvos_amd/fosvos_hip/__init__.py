@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 CONV_RELU = 1
 CONV_OUT_F32 = 2
 
@@ -78,6 +78,10 @@ SIGNATURES = {
                                      c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "fosvos_conv3x3_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_size_t, c_int, c_void_p]),
+    "fosvos_conv3x3_wgrad_slabs": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+                                           c_int, c_void_p]),
+    "fosvos_conv3x3_wgrad_reduce": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                            c_size_t, c_int, c_void_p]),
     "fosvos_conv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "fosvos_maxpool2x2_ceil_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fosvos_maxpool2x2_ceil_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -314,11 +314,31 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ci: int, co: int, with_bias
     _need(dw, _F32, "conv3x3_wgrad dw")
     ws, wsn = _WS.get(L.fosvos_conv3x3_wgrad_workspace_bytes(n, h, wd, ci, co), x.device)
     dev, st = _ctx(x)
+    # the two halves of fosvos_conv3x3_wgrad, timed apart: the MFMA kernel, then the slab reduction (memory-bound; the
+    # network call batches the reductions of all layers into two launches)
     t0 = _pb()
-    check(L.fosvos_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(db) if with_bias else None, n, h, wd, ci, co,
-                                 1 if accumulate else 0, ws, wsn, dev, st), "conv3x3_wgrad")
-    _pe(t0, "conv3x3_wgrad", 2.0 * n * h * wd * 9 * ci * co, n * h * wd * 2 * (ci + dy.shape[3]) + 4 * 9 * ci * co)
+    check(L.fosvos_conv3x3_wgrad_slabs(x.data_ptr(), dy.data_ptr(), 1 if with_bias else 0, n, h, wd, ci, co, ws, wsn, dev, st),
+          "conv3x3_wgrad_slabs")
+    _pe(t0, "conv3x3_wgrad", 2.0 * n * h * wd * 9 * ci * co, n * h * wd * 2 * (ci + dy.shape[3]))
+    t0 = _pb()
+    check(L.fosvos_conv3x3_wgrad_reduce(dw.data_ptr(), _p(db) if with_bias else None, n, h, wd, ci, co,
+                                        1 if accumulate else 0, ws, wsn, dev, st), "conv3x3_wgrad_reduce")
+    _pe(t0, "wgrad_reduce", 0.0, 4 * 9 * ci * co * 3)
     return dw, (db if with_bias else None)
+
+
+def conv3x3_wgrad_one_call(x: torch.Tensor, dy: torch.Tensor, ci: int, co: int, with_bias: bool = True):
+    """fosvos_conv3x3_wgrad: MFMA kernel and reduction behind one entry point (what a per-layer caller uses)."""
+    _need(x, _BF16, "conv3x3_wgrad x"); _need(dy, _BF16, "conv3x3_wgrad dy")
+    n, h, wd, _ = x.shape
+    L = lib()
+    dw = torch.empty((co, ci, 3, 3), dtype=_F32, device=x.device)
+    db = torch.empty((co,), dtype=_F32, device=x.device) if with_bias else None
+    ws, wsn = _WS.get(L.fosvos_conv3x3_wgrad_workspace_bytes(n, h, wd, ci, co), x.device)
+    dev, st = _ctx(x)
+    check(L.fosvos_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _p(db), n, h, wd, ci, co, 0, ws, wsn, dev, st),
+          "conv3x3_wgrad")
+    return dw, db
 
 
 # ------------------------------------------------------------------------------------------ pool

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 6
+#define FOSVOS_ABI_VERSION 7
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -135,6 +135,13 @@ int fosvos_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, float *dw_oihw, 
                          int Ci, int Co, int accumulate, void *workspace, size_t workspace_bytes, int device,
                          void *stream);
 size_t fosvos_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co);
+/* The two halves of fosvos_conv3x3_wgrad, for callers that batch or time them apart (the network call queues every
+ * layer's reduction and runs them together): _slabs runs the MFMA kernel, leaving per-split partial sums (and, with
+ * with_bias != 0, bias partials) in the workspace; _reduce turns that workspace into dw / db (db NULL = no bias). */
+int fosvos_conv3x3_wgrad_slabs(const uint16_t *x, const uint16_t *dy, int with_bias, int N, int H, int W, int Ci, int Co,
+                               void *workspace, size_t workspace_bytes, int device, void *stream);
+int fosvos_conv3x3_wgrad_reduce(float *dw_oihw, float *dbias, int N, int H, int W, int Ci, int Co, int accumulate,
+                                void *workspace, size_t workspace_bytes, int device, void *stream);
 
 /* ---- 2x2 stride-2 ceil-mode max pool on bf16 NHWC ---------------------------------------------
  * y[N,ceil(H/2),ceil(W/2),C]; ragged last row/column windows hold 2 or 1 elements.

@@ -279,6 +279,9 @@ def test_conv3x3_wgrad(ops, n, h, w, ci, co):
     dw2, db2 = ops.conv3x3_wgrad(to_nhwc_bf16(x), dy_dev, ci, co, dw=dw.clone(), db=db.clone(), accumulate=True)
     assert torch.equal(dw2, 2 * dw) and torch.equal(db2, 2 * db)
     dw3, _ = ops.conv3x3_wgrad(to_nhwc_bf16(x), dy_dev, ci, co)
+    # the one-call entry point (kernel + reduction) == the split calls the wrapper above uses, bit for bit
+    dw4, db4 = ops.conv3x3_wgrad_one_call(to_nhwc_bf16(x), dy_dev, ci, co)
+    assert torch.equal(dw4, dw) and torch.equal(db4, db)
     assert torch.equal(dw3, dw)
 
 
