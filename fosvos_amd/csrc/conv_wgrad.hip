@@ -141,11 +141,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         }
     };
 
-    if (t_begin < t_end) issue_tile(smem_w);
+    // Register-staged variant of the tile pipeline (main kernel; the conv1_1 KSPLIT kernel keeps the DMA above): an
+    // LDS-DMA piece costs the issuing wave ~100 clocks (1400 per tile, measured with a timing-only build), a
+    // global_load_dwordx4 + ds_write_b128 pair a third of that.  Tile t+1 is loaded into 4 + 6 named registers at the
+    // top of tile t (latency hidden by the MFMA loop) and written to the other image behind it.
+    constexpr bool REGSTAGE = !KSPLIT && CF <= 4;
+    uint4 py0, py1, py2, py3, px0, px1, px2, px3, px4, px5;
+    py0 = py1 = py2 = py3 = px0 = px1 = px2 = px3 = px4 = px5 = make_uint4(0, 0, 0, 0);
+#define FOSVOS_WG_LDY(cb_) \
+    if constexpr ((cb_) < CF) py##cb_ = *reinterpret_cast<const uint4 *>(y_ok_ ? (const void *)(ybase_ + y_off + (cb_) * 16) : zero);
+#define FOSVOS_WG_LDX(k_)                                                                               \
+    {                                                                                                   \
+        const int hy_ = x_rc[k_] >> 16, hx_ = x_rc[k_] & 0xffff;                                        \
+        const bool ok_ = hy_ >= 1 - y0_ && hy_ <= vrows_ && hx_ >= 1 - x0_ && hx_ <= vcols_;            \
+        px##k_ = *reinterpret_cast<const uint4 *>(ok_ ? (const void *)(xbase_ + x_off[k_]) : zero);     \
+    }
+#define FOSVOS_WG_LOAD_TILE()                                                                           \
+    {                                                                                                   \
+        const int y0_ = lt_y * TH, x0_ = lt_x * 16;                                                     \
+        const int vrows_ = H - y0_, vcols_ = W - x0_;                                                   \
+        const int64_t org_ = ((int64_t)lt_n * H + y0_) * W + x0_;                                       \
+        const uint16_t *ybase_ = a.dy + org_ * a.Cy;                                                    \
+        const uint16_t *xbase_ = a.x + org_ * a.Ci;                                                     \
+        const bool y_ok_ = y_ty < vrows_ && y_tx < vcols_;                                              \
+        FOSVOS_WG_LDY(0) FOSVOS_WG_LDY(1) FOSVOS_WG_LDY(2) FOSVOS_WG_LDY(3)                             \
+        FOSVOS_WG_LDX(0) FOSVOS_WG_LDX(1) FOSVOS_WG_LDX(2) FOSVOS_WG_LDX(3) FOSVOS_WG_LDX(4) FOSVOS_WG_LDX(5) \
+        if (++lt_x == a.tiles_x) {                                                                      \
+            lt_x = 0;                                                                                   \
+            if (++lt_y == a.tiles_y) { lt_y = 0; ++lt_n; }                                              \
+        }                                                                                               \
+    }
+#define FOSVOS_WG_STY(cb_, img_) \
+    if constexpr ((cb_) < CF) *reinterpret_cast<uint4 *>((img_) + ((cb_) * TPIX + wave * 32) * 32 + lane * 16) = py##cb_;
+#define FOSVOS_WG_STX(k_, img_) \
+    *reinterpret_cast<uint4 *>((img_) + Y_BYTES + (xblk * NPHP + (k_) * 32) * 32 + lane * 16) = px##k_;
+#define FOSVOS_WG_STORE_TILE(img_)                                                                      \
+    {                                                                                                   \
+        FOSVOS_WG_STY(0, img_) FOSVOS_WG_STY(1, img_) FOSVOS_WG_STY(2, img_) FOSVOS_WG_STY(3, img_)     \
+        FOSVOS_WG_STX(0, img_) FOSVOS_WG_STX(1, img_) FOSVOS_WG_STX(2, img_) FOSVOS_WG_STX(3, img_)     \
+        FOSVOS_WG_STX(4, img_) FOSVOS_WG_STX(5, img_)                                                   \
+    }
+
+    if constexpr (REGSTAGE) {
+        if (t_begin < t_end) {
+            FOSVOS_WG_LOAD_TILE()
+            FOSVOS_WG_STORE_TILE(smem_w)
+        }
+    } else {
+        if (t_begin < t_end) issue_tile(smem_w);
+    }
     __syncthreads();
     for (int tile = t_begin; tile < t_end; ++tile) {
         char *cur = smem_w + ((tile - t_begin) & 1) * BUF_BYTES;
-        if (tile + 1 < t_end) issue_tile(smem_w + (((tile - t_begin) & 1) ^ 1) * BUF_BYTES);
+        char *nxt = smem_w + (((tile - t_begin) & 1) ^ 1) * BUF_BYTES;
+        if constexpr (REGSTAGE) {
+            if (tile + 1 < t_end) FOSVOS_WG_LOAD_TILE()
+        } else {
+            if (tile + 1 < t_end) issue_tile(nxt);
+        }
         if (do_bias) {  // column sums of the dy tile: thread (cb = tid>>6, slot tid&63) keeps channels (cb, half) fixed
             if ((tid >> 6) < CF) {
 #pragma unroll
@@ -176,7 +229,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                     acc[i][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][tap], 0, 0, 0);
             }
         }
-        __syncthreads();  // drains the DMA of tile+1 (vmcnt(0)) and retires image `cur`
+        if constexpr (REGSTAGE) {
+            // image `nxt` was last read during tile-1 (every wave has passed that tile's barrier)
+            if (tile + 1 < t_end) FOSVOS_WG_STORE_TILE(nxt)
+        }
+        __syncthreads();  // tile+1 is in place (DMA path: drains it, vmcnt(0)) and image `cur` is retired
     }
     if (do_bias) {
         // 256 x 8 partials -> BCO channel sums in a fixed order: thread t owns channels (cb = t>>6, half = t&1)
