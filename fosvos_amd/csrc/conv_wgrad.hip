@@ -141,17 +141,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         }
     };
 
-    // Register-staged variant of the tile pipeline (main kernel; the conv1_1 KSPLIT kernel keeps the DMA above): an
+    // Register-staged tile pipeline (the LDS-DMA form above is kept for reference builds with more than 4 co blocks): an
     // LDS-DMA piece costs the issuing wave ~100 clocks (1400 per tile, measured with a timing-only build), a
     // global_load_dwordx4 + ds_write_b128 pair a third of that.  Tile t+1 is loaded into 4 + 6 named registers at the
     // top of tile t (latency hidden by the MFMA loop) and written to the other image behind it.
-    constexpr bool REGSTAGE = !KSPLIT && CF <= 4;
+    constexpr bool REGSTAGE = CF <= 4;
     uint4 py0, py1, py2, py3, px0, px1, px2, px3, px4, px5;
     py0 = py1 = py2 = py3 = px0 = px1 = px2 = px3 = px4 = px5 = make_uint4(0, 0, 0, 0);
 #define FOSVOS_WG_LDY(cb_) \
     if constexpr ((cb_) < CF) py##cb_ = *reinterpret_cast<const uint4 *>(y_ok_ ? (const void *)(ybase_ + y_off + (cb_) * 16) : zero);
 #define FOSVOS_WG_LDX(k_)                                                                               \
-    {                                                                                                   \
+    if (!KSPLIT || ((k_) & 3) == wave) { /* KSPLIT: the shared block's 6 groups are dealt over the 4 waves */ \
         const int hy_ = x_rc[k_] >> 16, hx_ = x_rc[k_] & 0xffff;                                        \
         const bool ok_ = hy_ >= 1 - y0_ && hy_ <= vrows_ && hx_ >= 1 - x0_ && hx_ <= vcols_;            \
         px##k_ = *reinterpret_cast<const uint4 *>(ok_ ? (const void *)(xbase_ + x_off[k_]) : zero);     \
@@ -173,8 +173,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
 #define FOSVOS_WG_STY(cb_, img_) \
     if constexpr ((cb_) < CF) *reinterpret_cast<uint4 *>((img_) + ((cb_) * TPIX + wave * 32) * 32 + lane * 16) = py##cb_;
-#define FOSVOS_WG_STX(k_, img_) \
-    *reinterpret_cast<uint4 *>((img_) + Y_BYTES + (xblk * NPHP + (k_) * 32) * 32 + lane * 16) = px##k_;
+#define FOSVOS_WG_STX(k_, img_)       \
+    if (!KSPLIT || ((k_) & 3) == wave) \
+        *reinterpret_cast<uint4 *>((img_) + Y_BYTES + (xblk * NPHP + (k_) * 32) * 32 + lane * 16) = px##k_;
 #define FOSVOS_WG_STORE_TILE(img_)                                                                      \
     {                                                                                                   \
         FOSVOS_WG_STY(0, img_) FOSVOS_WG_STY(1, img_) FOSVOS_WG_STY(2, img_) FOSVOS_WG_STY(3, img_)     \
