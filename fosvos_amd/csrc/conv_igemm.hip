@@ -495,9 +495,10 @@ ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
     auto blocks = [&](int th, int tw, int bn) { return cdiv(W, tw) * cdiv(H, th) * N * (int64_t)(out_ch / bn); };
     int64_t nb;
     if (out_ch % 64 == 0) {
-        // 256-pixel tiles as soon as they fill ~80 % of the 512 resident slots in ONE round (measured: 420
-        // workgroups of 8x32 beat 840 of 8x16 by 8 % at 120x214x256); below that the 128-pixel tile, 3 per CU
-        if (blocks(8, 32, 64) >= kMinBlocks * 4 / 5) { p.tile = kBig; nb = blocks(8, 32, 64); }
+        // 256-pixel tiles as soon as there is one per CU (measured: 420 workgroups of 8x32 beat 840 of 8x16 by 8 % at
+        // 120x214x256 alone; at 60x107x512, 256 of them beat 448 of 8x16 by 1 % of the whole step beside the wgrad
+        // stream, which fills the second slot of each CU); below that the 128-pixel tile, 3 per CU
+        if (blocks(8, 32, 64) >= kMinBlocks / 2) { p.tile = kBig; nb = blocks(8, 32, 64); }
         else { p.tile = kMid; nb = blocks(8, 16, 64); }
     } else {
         if (pixels >= 256 * 256) { p.tile = kSide; nb = blocks(8, 32, 16); }
