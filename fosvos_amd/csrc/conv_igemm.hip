@@ -360,31 +360,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))
     __syncthreads();
     FOSVOS_STAMP_AT(9)
     constexpr int VEC_PER_PIX = T::BN / 8;
+    constexpr int OUT_N = T::BM * VEC_PER_PIX;      // 16-byte output vectors of the tile
+    constexpr int OUT_IT = (OUT_N + 255) / 256;     // ... per thread
     uint16_t *yo = reinterpret_cast<uint16_t *>(a.y);
-    for (int idx = tid; idx < T::BM * VEC_PER_PIX; idx += 256) {
-        const int pix = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
-        const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
-        if (gy >= H || gx >= W) continue;
-        const int64_t off = (((int64_t)n * H + gy) * W + gx) * a.Cout + n0 + cg * 8;
-        uint4 v = *reinterpret_cast<const uint4 *>(sO + pix * T::OUT_LD + cg * 8);
-        if (a.relu_src || a.addend) {
+    if (a.relu_src || a.addend) {
+        // dgrad: ReLU mask of the producing layer and the other consumer's gradient.  ALL of a thread's mask / addend
+        // vectors are requested before the first one is used (unconditional loads from clamped addresses): rolled,
+        // this loop waited out one full memory latency per vector and operand (8 x 2 round trips per workgroup).
+        int64_t off[OUT_IT];
+        bool ok[OUT_IT];
+        uint4 mk[OUT_IT], ad[OUT_IT];
+#pragma unroll
+        for (int it = 0; it < OUT_IT; ++it) {
+            const int idx = min(it * 256 + tid, OUT_N - 1);
+            const int pix = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
+            const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
+            ok[it] = it * 256 + tid < OUT_N && gy < H && gx < W;
+            off[it] = (((int64_t)n * H + min(gy, H - 1)) * W + min(gx, W - 1)) * a.Cout + n0 + cg * 8;
+            mk[it] = ad[it] = make_uint4(0, 0, 0, 0);
+        }
+        if (a.relu_src) {
+#pragma unroll
+            for (int it = 0; it < OUT_IT; ++it) mk[it] = *reinterpret_cast<const uint4 *>(a.relu_src + off[it]);
+        }
+        if (a.addend) {
+#pragma unroll
+            for (int it = 0; it < OUT_IT; ++it) ad[it] = *reinterpret_cast<const uint4 *>(a.addend + off[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < OUT_IT; ++it) {
+            const int idx = min(it * 256 + tid, OUT_N - 1);
+            const int pix = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
             float f[8];
-            unpack8(v, f);
+            unpack8(*reinterpret_cast<const uint4 *>(sO + pix * T::OUT_LD + cg * 8), f);
             if (a.relu_src) {
                 float m[8];
-                unpack8(*reinterpret_cast<const uint4 *>(a.relu_src + off), m);
+                unpack8(mk[it], m);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = m[e] > 0.f ? f[e] : 0.f;
             }
             if (a.addend) {
-                float ad[8];
-                unpack8(*reinterpret_cast<const uint4 *>(a.addend + off), ad);
+                float av[8];
+                unpack8(ad[it], av);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] += ad[e];
+                for (int e = 0; e < 8; ++e) f[e] += av[e];
             }
-            v = pack8(f);
+            if (ok[it]) *reinterpret_cast<uint4 *>(yo + off[it]) = pack8(f);
         }
-        *reinterpret_cast<uint4 *>(yo + off) = v;
+    } else {
+#pragma unroll
+        for (int it = 0; it < OUT_IT; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx >= OUT_N) continue;
+            const int pix = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
+            const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
+            if (gy >= H || gx >= W) continue;
+            const int64_t off = (((int64_t)n * H + gy) * W + gx) * a.Cout + n0 + cg * 8;
+            *reinterpret_cast<uint4 *>(yo + off) = *reinterpret_cast<const uint4 *>(sO + pix * T::OUT_LD + cg * 8);
+        }
     }
     if (a.y_pool) {
         // fused MaxPool2d(2,2,ceil_mode=True) of this tile (tile origins and sizes are even, so no pooling window
