@@ -56,6 +56,10 @@ class OSVOS_VGG(nn.Module):
         # Opt-in for training loops that call ``loss.backward()`` (never ``torch.autograd.grad``): let the wgrad
         # kernels add straight into existing ``p.grad`` tensors instead of handing autograd a fresh tensor to add.
         self.accumulate_grads_in_place = False
+        # The four side logit maps (score_dsn -> upscale_ -> crop) are outputs of the reference's forward; the online
+        # loop only reads outputs[-1].  False skips them in the fused head (half of its arithmetic and 4 x 1.6 MB of
+        # writes per frame): forward then returns four EMPTY placeholder tensors in their place.
+        self.compute_side_outputs = True
 
         log.info("Initializing weights")
         self._initialize_weights(pretrained)
@@ -64,7 +68,7 @@ class OSVOS_VGG(nn.Module):
     def forward(self, x):
         """list of 5 logit maps [N,1,H,W]: the 4 side outputs then the fused output."""
         params = self._ordered_params()
-        return engine.run(self._packs, params, x, with_side_out=True,
+        return engine.run(self._packs, params, x, with_side_out=bool(getattr(self, 'compute_side_outputs', True)),
                           inplace_grad=getattr(self, 'accumulate_grads_in_place', False))
 
     def join_gradients(self):
@@ -100,6 +104,8 @@ class OSVOS_VGG(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state.pop('_packs', None)  # whole-module pickles (NetworkProvider.save_model) carry no device caches
+        state['compute_side_outputs'] = True        # ... and no loop-local switches (a snapshot taken inside _train)
+        state['accumulate_grads_in_place'] = False
         return state
 
     def __setstate__(self, state):

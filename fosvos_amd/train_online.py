@@ -78,6 +78,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     log.info('Start of Online Training, sequence: ' + seq_name)
     net = net_provider.network
     net.accumulate_grads_in_place = True  # this loop only ever calls loss.backward()
+    net.compute_side_outputs = False      # ... on outputs[-1] only (src/train_online.py:80): skip the 4 side logit maps
     # weights are constant inside an accumulation cycle: let the next forward overlap the wgrad tail of this backward
     net.defer_wgrad_join = os.environ.get('FOSVOS_DEFER_JOIN', '1') != '0'
     world = parallel.world_size() if data_parallel else 1
@@ -132,6 +133,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             net_provider.save_model(epoch, sequence=seq_name)
 
     net.defer_wgrad_join = False  # joins
+    net.compute_side_outputs = True
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     time_for_all = timeit.default_timer() - time_all_start
