@@ -29,19 +29,38 @@ __global__ __launch_bounds__(256) void k_first_fwd(const float *__restrict__ fra
     const int y0 = blockIdx.y * ROWS;
     const int x0 = blockIdx.x * TW;
     const int tid = threadIdx.x;
-    for (int i = tid; i < 27 * CO; i += 256) {
-        const int co = i % CO, k = i / CO;  // k = ci*9 + tap
-        s_w[k][co] = w[co * 27 + k];
-    }
-    const int64_t plane = (int64_t)H * W;
-    for (int i = tid; i < 3 * (ROWS + 2) * (TW + 8); i += 256) {
-        const int xx = i % (TW + 8);
-        const int r = (i / (TW + 8)) % (ROWS + 2);
-        const int c = i / ((TW + 8) * (ROWS + 2));
-        const int gy = y0 + r - 1, gx = x0 + xx - 4;
-        float v = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = frame[((int64_t)n * 3 + c) * plane + (int64_t)gy * W + gx];
-        s_in[c][r][xx] = v;
+    // staging: all of a thread's global loads are issued before its first LDS store (unconditional loads from
+    // clamped addresses); rolled, each element waited out its own memory round trip (7 + 3 in a row per thread)
+    {
+        constexpr int WN = 27 * CO, WIT = (WN + 255) / 256, IN = 3 * (ROWS + 2) * (TW + 8), IIT = (IN + 255) / 256;
+        float tw[WIT], ti[IIT];
+        bool oki[IIT];
+        const int64_t plane = (int64_t)H * W;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = min(it * 256 + tid, WN - 1);
+            tw[it] = w[(i % CO) * 27 + i / CO];  // s_w[k = ci*9 + tap][co]
+        }
+#pragma unroll
+        for (int it = 0; it < IIT; ++it) {
+            const int i = min(it * 256 + tid, IN - 1);
+            const int xx = i % (TW + 8);
+            const int r = (i / (TW + 8)) % (ROWS + 2);
+            const int c = i / ((TW + 8) * (ROWS + 2));
+            const int gy = y0 + r - 1, gx = x0 + xx - 4;
+            oki[it] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            ti[it] = frame[((int64_t)n * 3 + c) * plane + (int64_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)];
+        }
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = it * 256 + tid;
+            if (i < WN) s_w[i / CO][i % CO] = tw[it];
+        }
+#pragma unroll
+        for (int it = 0; it < IIT; ++it) {
+            const int i = it * 256 + tid;
+            if (i < IN) (&s_in[0][0][0])[i] = oki[it] ? ti[it] : 0.f;
+        }
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;

@@ -460,11 +460,23 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int64
         float f[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = 0.f;
-        for (int z = 0; z < a.k_splits; ++z) {
-            const float4 v0 = *reinterpret_cast<const float4 *>(a.partial + z * plane + off);
-            const float4 v1 = *reinterpret_cast<const float4 *>(a.partial + z * plane + off + 4);
-            f[0] += v0.x; f[1] += v0.y; f[2] += v0.z; f[3] += v0.w;
-            f[4] += v1.x; f[5] += v1.y; f[6] += v1.z; f[7] += v1.w;
+        // the partial planes are requested four at a time before they are added (in increasing z): a rolled loop
+        // waited out one memory round trip per plane
+        for (int z0 = 0; z0 < a.k_splits; z0 += 4) {
+            float4 v0[4], v1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int z = min(z0 + j, a.k_splits - 1);
+                v0[j] = *reinterpret_cast<const float4 *>(a.partial + z * plane + off);
+                v1[j] = *reinterpret_cast<const float4 *>(a.partial + z * plane + off + 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (z0 + j < a.k_splits) {
+                    f[0] += v0[j].x; f[1] += v0[j].y; f[2] += v0[j].z; f[3] += v0[j].w;
+                    f[4] += v1[j].x; f[5] += v1[j].y; f[6] += v1[j].z; f[7] += v1[j].w;
+                }
+            }
         }
         if (a.bias) {
 #pragma unroll

@@ -198,15 +198,40 @@ __global__ __launch_bounds__(256) void k_head_bwd_scale(const float *__restrict_
     const int tid = threadIdx.x;
     const int n = blockIdx.z, i0 = blockIdx.y * TI, j0 = blockIdx.x * TJ;
     const int Y0 = i0 * f - top, X0 = j0 * f - left;
-    for (int e = tid; e < k * k * 4; e += 256)
-        reinterpret_cast<float4 *>(sF)[e] = reinterpret_cast<const float4 *>(filt)[e];
-    for (int e = tid; e < WR * WC; e += 256) {
-        const int r = e / WC, cidx = e - r * WC;
-        const int Y = Y0 + r, X = X0 + cidx;
-        const bool ok = Y >= 0 && Y < H && X >= 0 && X < W;
-        const int64_t off = ((int64_t)n * H + Y) * W + X;
-        sW[e] = (ok && d_fused) ? d_fused[off] : 0.f;
-        if (WITH_SIDE_OUT) sW1[e] = ok ? d_so[off] : 0.f;
+    // Staging: every global load of a thread is issued before the first LDS store (unconditional loads from clamped
+    // addresses).  Rolled, these loops waited out one memory round trip per element: 16 + 27 in a row at scale 3,
+    // which was the whole 24 us of the kernel.
+    {
+        constexpr int FN = k * k * 4, FIT = (FN + 255) / 256;
+        float4 tf[FIT];
+#pragma unroll
+        for (int it = 0; it < FIT; ++it) tf[it] = reinterpret_cast<const float4 *>(filt)[min(it * 256 + tid, FN - 1)];
+#pragma unroll
+        for (int it = 0; it < FIT; ++it)
+            if (it * 256 + tid < FN) reinterpret_cast<float4 *>(sF)[it * 256 + tid] = tf[it];
+    }
+    {
+        constexpr int WN = WR * WC, WIT = (WN + 255) / 256;
+        float tw[WIT], tw1[WITH_SIDE_OUT ? WIT : 1];
+        bool okv[WIT];
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int e = min(it * 256 + tid, WN - 1);
+            const int r = e / WC, cidx = e - r * WC;
+            const int Y = Y0 + r, X = X0 + cidx;
+            okv[it] = Y >= 0 && Y < H && X >= 0 && X < W;
+            const int64_t off = ((int64_t)n * H + min(max(Y, 0), H - 1)) * W + min(max(X, 0), W - 1);
+            tw[it] = d_fused ? d_fused[off] : 0.f;
+            if (WITH_SIDE_OUT) tw1[it] = d_so[off];
+        }
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int e = it * 256 + tid;
+            if (e < WN) {
+                sW[e] = okv[it] ? tw[it] : 0.f;
+                if (WITH_SIDE_OUT) sW1[e] = okv[it] ? tw1[it] : 0.f;
+            }
+        }
     }
     if (WITH_SIDE_OUT)
         for (int e = tid; e < k * k; e += 256) sF1[e] = filt1[e];
