@@ -121,10 +121,24 @@ __global__ __launch_bounds__(64) void k_finish(int64_t n, int size_average, cons
     // lane t sums entries t, t+64, ... then a fixed butterfly: the order never changes run to run
     unsigned long long np = 0;
     double pos = 0.0, neg = 0.0;
-    for (int b = threadIdx.x; b < n_blocks; b += 64) {
-        np += ws->count[b];
-        pos += ws->pos[b];
-        neg += ws->neg[b];
+    for (int b0 = threadIdx.x; b0 < n_blocks; b0 += 64 * 8) {  // 8 entries in flight (same order of additions)
+        unsigned long long c[8];
+        double p[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int b = min(b0 + 64 * j, n_blocks - 1);
+            c[j] = ws->count[b];
+            p[j] = ws->pos[b];
+            q[j] = ws->neg[b];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (b0 + 64 * j < n_blocks) {
+                np += c[j];
+                pos += p[j];
+                neg += q[j];
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) np += __shfl_xor(np, o, 64);
