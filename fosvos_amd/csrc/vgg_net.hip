@@ -248,15 +248,23 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
             }
             const bool from_pool = (c == first) && s > 0;  // its input is the pool output; conv 1 reads conv 0
             const uint16_t *xin = from_pool ? reinterpret_cast<const uint16_t *>(base + a.pooled[s - 1]) : act(c - 1);
-            FOSVOS_TRY(wgrad_impl(xin, gact(c), g->conv_w[c], g->conv_b[c], N, hh, ww, kCin[c], kCout[c], acc,
-                                  base + a.wsa_conv[c], a.wsa_conv_bytes[c], device, sa, &reduce));
             // dgrad: into the previous conv's output gradient (masked by its ReLU), or into the pool-output gradient
             // (unmasked: the pool backward applies the producer's mask)
             uint16_t *dx = from_pool ? reinterpret_cast<uint16_t *>(base + a.gpooled[s - 1]) : gact(c - 1);
             const uint16_t *mask = from_pool ? nullptr : act(c - 1);
+            // In a 3-conv stage the middle conv's gradient gets no event of its own (an event costs ~3 us of main-stream
+            // time): its dgrad is issued first and the event behind it covers both gact(c) and gact(c-1).
+            const bool middle = (last - first == 2) && c == last - 1;
+            if (!middle)
+                FOSVOS_TRY(wgrad_impl(xin, gact(c), g->conv_w[c], g->conv_b[c], N, hh, ww, kCin[c], kCout[c], acc,
+                                      base + a.wsa_conv[c], a.wsa_conv_bytes[c], device, sa, &reduce));
             FOSVOS_TRY(fosvos_conv3x3_dgrad(gact(c), w->conv_wd[c], mask, nullptr, dx, N, hh, ww, kCin[c], kCout[c], ws,
                                             a.ws_bytes, device, sm));
-            if (!from_pool) FOSVOS_TRY(publish(c - 1));
+            const bool skip_event = (last - first == 2) && c == last;  // gact(last-1): covered by the middle conv's event
+            if (!from_pool && !skip_event) FOSVOS_TRY(publish(c - 1));
+            if (middle)
+                FOSVOS_TRY(wgrad_impl(xin, gact(c), g->conv_w[c], g->conv_b[c], N, hh, ww, kCin[c], kCout[c], acc,
+                                      base + a.wsa_conv[c], a.wsa_conv_bytes[c], device, sa, &reduce));
         }
         if (s > 0)  // pool backward into the previous stage's output gradient, its ReLU mask fused
             FOSVOS_TRY(fosvos_maxpool2x2_ceil_bwd(act(kLastOfStage[s - 1]), reinterpret_cast<const uint16_t *>(base + a.gpooled[s - 1]),
