@@ -523,11 +523,11 @@ int fosvos::wgrad_impl(const uint16_t *x, const uint16_t *dy, float *dw, float *
     // two tile images (dy + x) per workgroup; never less than the bias scratch [256][9] floats
     auto lds_bytes = [](int cf) { return (size_t)2 * (cf * TPIX + 4 * NPHP) * 32; };
     if (p.bco == 64) {
-        static bool once = false;
-        if (!once) {
+        static bool once[64];  // per device: opt in to 80 KB of dynamic LDS
+        if (device >= 0 && device < 64 && !once[device]) {
             FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad<64>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(4)));
-            once = true;
+            once[device] = true;
         }
         hipLaunchKernelGGL(k_wgrad<64>, grid, dim3(256), lds_bytes(4), st, a);
     } else if (p.bco == 32) {
