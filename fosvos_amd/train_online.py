@@ -93,6 +93,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     log_every = max(n_epochs // 20, 1)  # the reference divides by n_epochs // 20, which is 0 below 20 epochs
     device = next(net.parameters()).device
     running_loss_tr = torch.zeros((), device=device)
+    inv_avg = torch.ones((), device=device) / avg_grad_every_n
 
     time_all_start = timeit.default_timer()
     n_iters = 0
@@ -114,8 +115,10 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
                 log.info('Loss {0}: {1}'.format(seq_name, value))
                 summary_writer.add_scalar('data/total_loss_epoch', value, epoch)
 
-            loss = loss / avg_grad_every_n
-            loss.backward()
+            # reference: `loss /= nAveGrad; loss.backward()` (src/train_online.py:92-93).  Seeding the backward pass with
+            # 1/nAveGrad is the same gradient (the division's own backward produces exactly this factor) without the
+            # three tiny kernels of the division, the ones-fill and its backward on the critical path
+            loss.backward(inv_avg)
             # (the reference also sums loss.item() into a per-epoch tensorboard scalar, src/train_online.py:94-104: one
             # device sync per frame; running_loss_tr above carries the same information without it)
             counter_gradient += 1
