@@ -95,6 +95,22 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     running_loss_tr = torch.zeros((), device=device)
     inv_avg = torch.ones((), device=device) / avg_grad_every_n
 
+    pending_logs = []
+
+    def flush_logs(block: bool) -> None:
+        while pending_logs:
+            ep, mb, host_val, landed = pending_logs[0]
+            if block:
+                landed.synchronize()
+            elif not landed.query():
+                break
+            pending_logs.pop(0)
+            value = float(host_val) / n_samples
+            loss_tr.append(value)
+            log.info('[Epoch {0}: {1}, numImages: {2}]'.format(seq_name, ep + 1, mb + 1))
+            log.info('Loss {0}: {1}'.format(seq_name, value))
+            summary_writer.add_scalar('data/total_loss_epoch', value, ep)
+
     time_all_start = timeit.default_timer()
     n_iters = 0
     for epoch in range(start_epoch, n_epochs):
@@ -108,12 +124,15 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             running_loss_tr += loss.detach()
 
             if epoch % log_every == log_every - 1:
-                value = float(running_loss_tr) / n_samples  # the only device->host sync of the loop
-                loss_tr.append(value)
+                # the reference reads the running loss here (a device->host sync that drains the launch queue 20 times
+                # per run); the value is copied to pinned memory asynchronously instead and logged once it has landed
+                host_val = torch.empty((), dtype=torch.float32, pin_memory=True)
+                host_val.copy_(running_loss_tr, non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record()
+                pending_logs.append((epoch, minibatch_index, host_val, landed))
                 running_loss_tr.zero_()
-                log.info('[Epoch {0}: {1}, numImages: {2}]'.format(seq_name, epoch + 1, minibatch_index + 1))
-                log.info('Loss {0}: {1}'.format(seq_name, value))
-                summary_writer.add_scalar('data/total_loss_epoch', value, epoch)
+                flush_logs(False)
 
             # reference: `loss /= nAveGrad; loss.backward()` (src/train_online.py:92-93).  Seeding the backward pass with
             # 1/nAveGrad is the same gradient (the division's own backward produces exactly this factor) without the
@@ -139,6 +158,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     net.compute_side_outputs = True
     if torch.cuda.is_available():
         torch.cuda.synchronize()
+    flush_logs(True)
     time_for_all = timeit.default_timer() - time_all_start
     n_images = len(dataloader)
     log.info('Train {0}: total time {1} sec'.format(seq_name, str(time_for_all)))
