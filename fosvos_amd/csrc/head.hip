@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadPtrs p, HeadGeom g, const 
             dw[c] = s_dw[16 * s + c];
         }
         float so_acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+#pragma unroll 4
         for (int ab = 0; ab < 4; ++ab) {
             const int a = ab >> 1, b = ab & 1;
             const int i = i1 - a, ky = ky1 + a * f, kx = kx1 + b * f;
