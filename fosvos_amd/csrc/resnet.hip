@@ -1,0 +1,512 @@
+// Inference kernels of the thin-channel ResNet family (OSVOS_RESNET: src/networks/osvos_resnet.py:15-150, and the
+// filter-pruned nets src/prune.py:297-481 derives from it).  Eval-mode BatchNorm is folded into the conv
+// that feeds it when the weights are packed, the residual add and the ReLU ride in the conv epilogue.
+//
+// These layers are thin (8..128 channels once scale_down_exponent or pruning has been applied) and their channel counts
+// are arbitrary, so they do not go through the MFMA implicit GEMM (Ci % 32, Co % 64).  The contraction runs on the vector
+// ALU instead, two bf16 products per lane and clock (v_dot2c_f32_bf16, fp32 accumulate):
+//   * a thread owns ONE output pixel and COB output channels (8..64 accumulators);
+//   * activations are bf16 NHWC with the channel count padded to a multiple of 8, so a tap of 8 input channels is one
+//     16-byte load per thread, straight from global memory (neighbouring threads share taps through L1; the maps of a
+//     thin net fit L2);
+//   * weights are the same for every lane of a wave: they are indexed by block and loop counters only, so hipcc fetches
+//     them with scalar loads and feeds them to the dot instruction as its SGPR operand - no LDS, no broadcast reads.
+// Padded channels hold exact zeros everywhere (zero weights and bias), so no kernel ever masks a channel.
+#include "common.hpp"
+
+using namespace fosvos;
+
+namespace {
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t w, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, w), acc, false);
+}
+
+// ------------------------------------------------------------------------------------------ weight packing
+// OIHW fp32 -> [ci chunk of 8][tap][ci pair][Cop] dwords (low half = even input channel), scaled by the BatchNorm that
+// follows the conv; bias_out[co] = bn_bias - mean * s (+ conv_bias * s), s = bn_weight / sqrt(var + eps).
+__global__ void k_pack_conv2d_bn(const float *__restrict__ w, int Co, int Ci, int k, const float *__restrict__ conv_bias,
+                                 const float *__restrict__ bn_w, const float *__restrict__ bn_b,
+                                 const float *__restrict__ bn_m, const float *__restrict__ bn_v, float eps,
+                                 uint32_t *__restrict__ wp, float *__restrict__ bias_out, int Cop, int cic, int64_t total,
+                                 int bias_len) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < bias_len) {
+        float b = 0.f;
+        if (i < Co) {
+            const float s = bn_w ? bn_w[i] / sqrtf(bn_v[i] + eps) : 1.f;
+            b = (bn_w ? bn_b[i] - bn_m[i] * s : 0.f) + (conv_bias ? conv_bias[i] * s : 0.f);
+        }
+        bias_out[i] = b;
+    }
+    if (i >= total) return;
+    const int T = k * k;
+    const int co = (int)(i % Cop);
+    int64_t r = i / Cop;
+    const int p = (int)(r & 3);
+    r >>= 2;
+    const int t = (int)(r % T);
+    const int c = (int)(r / T);
+    uint32_t v = 0;
+    if (c < cic && co < Co) {
+        const float s = bn_w ? bn_w[co] / sqrtf(bn_v[co] + eps) : 1.f;
+        const int ci = c * 8 + p * 2;
+        const float lo = ci < Ci ? w[((int64_t)co * Ci + ci) * T + t] * s : 0.f;
+        const float hi = ci + 1 < Ci ? w[((int64_t)co * Ci + ci + 1) * T + t] * s : 0.f;
+        v = pack2bf(lo, hi);
+    }
+    wp[i] = v;
+}
+
+// First layer: [Co][3][7][7] fp32 -> [tap * 3 + ci][Cop] fp32 (the frame stays fp32, so do the weights).
+__global__ void k_pack_conv7x7_bn(const float *__restrict__ w, int Co, const float *__restrict__ bn_w,
+                                  const float *__restrict__ bn_b, const float *__restrict__ bn_m,
+                                  const float *__restrict__ bn_v, float eps, float *__restrict__ wp,
+                                  float *__restrict__ bias_out, int Cop, int total, int bias_len) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < bias_len) {
+        float b = 0.f;
+        if (i < Co && bn_w) b = bn_b[i] - bn_m[i] * bn_w[i] / sqrtf(bn_v[i] + eps);
+        bias_out[i] = b;
+    }
+    if (i >= total) return;
+    const int co = i % Cop, r = i / Cop;  // r = tap * 3 + ci
+    float v = 0.f;
+    if (r < 147 && co < Co) {
+        const int ci = r % 3, t = r / 3;
+        const float s = bn_w ? bn_w[co] / sqrtf(bn_v[co] + eps) : 1.f;
+        v = w[((int64_t)co * 3 + ci) * 49 + t] * s;
+    }
+    wp[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------ k x k conv, stride S
+template <int KS, int S, int COB, bool OUT_F32>
+__global__ __launch_bounds__(256) void k_conv2d(const uint4 *__restrict__ x, const uint32_t *__restrict__ wp,
+                                                const float *__restrict__ bias, const uint4 *__restrict__ addend,
+                                                void *__restrict__ y, int N, int H, int W, int Ho, int Wo, int cic,
+                                                int Cop, int relu) {
+    constexpr int P = KS / 2, T = KS * KS;
+    const int64_t npix = (int64_t)N * Ho * Wo;
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = pix < npix;
+    const int64_t pc = live ? pix : npix - 1;
+    const int ox = (int)(pc % Wo), oy = (int)((pc / Wo) % Ho), n = (int)(pc / ((int64_t)Wo * Ho));
+    const int cb = blockIdx.y;
+
+    int off[T];
+    bool ok[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int iy = oy * S + t / KS - P, ix = ox * S + t % KS - P;
+        ok[t] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        off[t] = ((n * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * cic;
+    }
+    float acc[COB];
+#pragma unroll
+    for (int j = 0; j < COB; ++j) acc[j] = 0.f;
+
+    const uint32_t *wb = wp + cb * COB;
+    for (int c = 0; c < cic; ++c) {
+        uint4 a[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            a[t] = x[off[t] + c];
+            if (!ok[t]) a[t] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const uint32_t *wt = wb + (int64_t)((c * T + t) * 4) * Cop;  // uniform across the wave: scalar loads
+            const uint32_t av[4] = {a[t].x, a[t].y, a[t].z, a[t].w};
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int j = 0; j < COB; ++j) acc[j] = dot2(av[p], wt[p * Cop + j], acc[j]);
+        }
+    }
+    if (!live) return;
+    const int cop8 = Cop >> 3;
+#pragma unroll
+    for (int g = 0; g < COB / 8; ++g) {
+        const int co8 = cb * (COB / 8) + g;
+        if (co8 >= cop8) break;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[g * 8 + e] + bias[cb * COB + g * 8 + e];
+        if (addend) {
+            float r[8];
+            unpack8(addend[pix * cop8 + co8], r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (OUT_F32) {
+            float4 *o = reinterpret_cast<float4 *>(y) + (pix * cop8 + co8) * 2;
+            o[0] = make_float4(v[0], v[1], v[2], v[3]);
+            o[1] = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            reinterpret_cast<uint4 *>(y)[pix * cop8 + co8] = pack8(v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 7x7 stride-2 first layer
+// frame fp32 NCHW [N,3,H,W] -> bf16 NHWC [N,Ho,Wo,Cop]; fp32 multiply-add with the weights as scalar operands.
+template <int COB>
+__global__ __launch_bounds__(256) void k_conv7x7s2_first(const float *__restrict__ frame, const float *__restrict__ wp,
+                                                         const float *__restrict__ bias, uint4 *__restrict__ y, int N,
+                                                         int H, int W, int Ho, int Wo, int Cop, int relu) {
+    const int64_t npix = (int64_t)N * Ho * Wo;
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = pix < npix;
+    const int64_t pc = live ? pix : npix - 1;
+    const int ox = (int)(pc % Wo), oy = (int)((pc / Wo) % Ho), n = (int)(pc / ((int64_t)Wo * Ho));
+    const int cb = blockIdx.y;
+    const int64_t plane = (int64_t)H * W;
+    const float *f0 = frame + (int64_t)n * 3 * plane;
+    float acc[COB];
+#pragma unroll
+    for (int j = 0; j < COB; ++j) acc[j] = 0.f;
+#pragma unroll 1
+    for (int ky = 0; ky < 7; ++ky) {
+        const int iy = oy * 2 + ky - 3;
+        const bool row_ok = iy >= 0 && iy < H;
+        const float *frow = f0 + (int64_t)min(max(iy, 0), H - 1) * W;
+        float v[21];
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            const int ix = ox * 2 + kx - 3;
+            const bool ok = row_ok && ix >= 0 && ix < W;
+            const int ixc = min(max(ix, 0), W - 1);
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float t = frow[ci * plane + ixc];
+                v[kx * 3 + ci] = ok ? t : 0.f;
+            }
+        }
+        const float *wr = wp + (int64_t)(ky * 21) * Cop + cb * COB;  // uniform: scalar loads
+#pragma unroll
+        for (int q = 0; q < 21; ++q)
+#pragma unroll
+            for (int j = 0; j < COB; ++j) acc[j] = fmaf(v[q], wr[q * Cop + j], acc[j]);
+    }
+    if (!live) return;
+    const int cop8 = Cop >> 3;
+#pragma unroll
+    for (int g = 0; g < COB / 8; ++g) {
+        const int co8 = cb * (COB / 8) + g;
+        if (co8 >= cop8) break;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = acc[g * 8 + e] + bias[cb * COB + g * 8 + e];
+            if (relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        y[pix * cop8 + co8] = pack8(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 3x3 stride-2 max pool, pad 1
+__global__ __launch_bounds__(256) void k_maxpool3x3s2(const uint4 *__restrict__ x, uint4 *__restrict__ y, int N, int H,
+                                                      int W, int Ho, int Wo, int c8) {
+    const int64_t total = (int64_t)N * Ho * Wo * c8;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int g = (int)(i % c8);
+    int64_t r = i / c8;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho), n = (int)(r / Ho);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int iy = oy * 2 + dy;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int ix = ox * 2 + dx;
+            if (ix < 0 || ix >= W) continue;
+            float v[8];
+            unpack8(x[(((int64_t)n * H + iy) * W + ix) * c8 + g], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+        }
+    }
+    y[i] = pack8(m);
+}
+
+// ------------------------------------------------------------------------------------------ side-output head
+// Four scales of transposed conv (kernel 2f, stride f), centre crop, concat and 1x1 fuse, with the 16 -> 16 upscale
+// filter and the fuse weights already contracted into one [k][k][16] filter per scale on the host (both are linear).
+struct DeconvHeadArgs {
+    const float *side[4];
+    const float *filt[4];
+    const float *filt1[4];
+    float *side_out[4];
+    float *fused;
+    const float *dsn_w, *dsn_b, *fuse_b;
+    int hs[4], ws[4], f[4], top[4], left[4];
+    int N, H, W, with_side_out;
+};
+
+__global__ __launch_bounds__(256) void k_deconv_head(const DeconvHeadArgs g) {
+    const int X = blockIdx.x * 64 + threadIdx.x, Y = blockIdx.y * 4 + threadIdx.y, n = blockIdx.z;
+    if (X >= g.W || Y >= g.H) return;
+    float fused = g.fuse_b[0];
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+        const int f = g.f[s], k = 2 * f, hs = g.hs[s], ws = g.ws[s];
+        const int yy = Y + g.top[s], xx = X + g.left[s];
+        const int i0 = yy / f, ky0 = yy - i0 * f, j0 = xx / f, kx0 = xx - j0 * f;
+        float dw[16];
+        float db = 0.f;
+        if (g.with_side_out) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dw[c] = g.dsn_w[s * 16 + c];
+            db = g.dsn_b[s];
+        }
+        float so = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int i = i0 - a, ky = ky0 + a * f;
+            if (i < 0 || i >= hs) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int j = j0 - b, kx = kx0 + b * f;
+                if (j < 0 || j >= ws) continue;
+                const float4 *sp = reinterpret_cast<const float4 *>(g.side[s]) + (((int64_t)n * hs + i) * ws + j) * 4;
+                const float4 *fp = reinterpret_cast<const float4 *>(g.filt[s]) + ((int64_t)ky * k + kx) * 4;
+                float d = db;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 sv = sp[q], fv = fp[q];
+                    fused = fmaf(sv.x, fv.x, fused);
+                    fused = fmaf(sv.y, fv.y, fused);
+                    fused = fmaf(sv.z, fv.z, fused);
+                    fused = fmaf(sv.w, fv.w, fused);
+                    if (g.with_side_out) {
+                        d = fmaf(sv.x, dw[q * 4 + 0], d);
+                        d = fmaf(sv.y, dw[q * 4 + 1], d);
+                        d = fmaf(sv.z, dw[q * 4 + 2], d);
+                        d = fmaf(sv.w, dw[q * 4 + 3], d);
+                    }
+                }
+                if (g.with_side_out) so = fmaf(g.filt1[s][ky * k + kx], d, so);
+            }
+        }
+        if (g.with_side_out) g.side_out[s][((int64_t)n * g.H + Y) * g.W + X] = so;
+    }
+    g.fused[((int64_t)n * g.H + Y) * g.W + X] = fused;
+}
+
+// ------------------------------------------------------------------------------------------ launch planning
+// Output-channel block of a launch: the widest of 64/32/16/8 that wastes at most an eighth of its lanes on channel
+// padding and still gives the chip 8 waves per CU; thin or deep layers fall back to narrower blocks (more waves).
+struct ConvLaunch {
+    int cob, threads;
+};
+ConvLaunch plan_conv2d(int64_t npix, int Cop) {
+    const int cand[4] = {64, 32, 16, 8};
+    int pick = 8;
+    for (int q = 0; q < 4; ++q) {
+        const int cob = cand[q], nb = (Cop + cob - 1) / cob;
+        if (cob != 8 && (nb * cob - Cop) * 8 > Cop) continue;
+        pick = cob;
+        if (cdiv(npix, 64) * nb >= 2048) break;
+    }
+    const int nb = (Cop + pick - 1) / pick;
+    return {pick, cdiv(npix, 256) * nb >= 1024 ? 256 : 64};
+}
+
+template <int KS, int S, bool OUT_F32>
+void launch_conv2d(const ConvLaunch &L, dim3 grid, hipStream_t st, const uint4 *x, const uint32_t *wp, const float *bias,
+                   const uint4 *addend, void *y, int N, int H, int W, int Ho, int Wo, int cic, int Cop, int relu) {
+#define FOSVOS_GO(COB)                                                                                                 \
+    hipLaunchKernelGGL((k_conv2d<KS, S, COB, OUT_F32>), grid, dim3(L.threads), 0, st, x, wp, bias, addend, y, N, H, W, Ho, \
+                       Wo, cic, Cop, relu)
+    switch (L.cob) {
+        case 64: FOSVOS_GO(64); break;
+        case 32: FOSVOS_GO(32); break;
+        case 16: FOSVOS_GO(16); break;
+        default: FOSVOS_GO(8); break;
+    }
+#undef FOSVOS_GO
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" size_t fosvos_conv2d_packed_dwords(int out_ch, int in_ch, int k) {
+    if (out_ch <= 0 || in_ch <= 0 || (k != 1 && k != 3)) return 0;
+    return (size_t)(roundup(in_ch, 8) / 8) * k * k * 4 * roundup(out_ch, 8) + 64;  // + slack a partial block may read
+}
+extern "C" size_t fosvos_conv2d_bias_elems(int out_ch) { return out_ch > 0 ? (size_t)roundup(out_ch, 64) + 64 : 0; }
+
+extern "C" int fosvos_pack_conv2d_bn(const float *w_oihw, int Co, int Ci, int k, const float *conv_bias,
+                                     const float *bn_weight, const float *bn_bias, const float *bn_mean,
+                                     const float *bn_var, float eps, uint32_t *w_packed, float *bias_out, int device,
+                                     void *stream) {
+    FOSVOS_REQUIRE(w_oihw && w_packed && bias_out, FOSVOS_E_ARG, "pack_conv2d_bn: null pointer");
+    FOSVOS_REQUIRE(Co > 0 && Ci > 0 && (k == 1 || k == 3), FOSVOS_E_ARG, "pack_conv2d_bn: Co=%d Ci=%d k=%d", Co, Ci, k);
+    FOSVOS_REQUIRE(!bn_weight || (bn_bias && bn_mean && bn_var), FOSVOS_E_ARG, "pack_conv2d_bn: partial BatchNorm");
+    FOSVOS_ENTER(device);
+    const int Cop = roundup(Co, 8), cic = roundup(Ci, 8) / 8;
+    const int64_t total = (int64_t)fosvos_conv2d_packed_dwords(Co, Ci, k);
+    const int bias_len = (int)fosvos_conv2d_bias_elems(Co);
+    const int64_t n = std::max<int64_t>(total, bias_len);
+    hipLaunchKernelGGL(k_pack_conv2d_bn, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, Co, Ci, k,
+                       conv_bias, bn_weight, bn_bias, bn_mean, bn_var, eps, w_packed, bias_out, Cop, cic, total, bias_len);
+    FOSVOS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fosvos_conv2d_fwd(const uint16_t *x, const uint32_t *w_packed, const float *bias, const uint16_t *addend,
+                                 void *y, int N, int H, int W, int Ci, int Co, int k, int stride, unsigned flags,
+                                 int device, void *stream) {
+    FOSVOS_REQUIRE(x && w_packed && bias && y, FOSVOS_E_ARG, "conv2d_fwd: null pointer");
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, FOSVOS_E_ARG, "conv2d_fwd: N=%d H=%d W=%d Ci=%d Co=%d", N,
+                   H, W, Ci, Co);
+    FOSVOS_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), FOSVOS_E_SHAPE,
+                   "conv2d_fwd: k=%d stride=%d (1 or 3, 1 or 2)", k, stride);
+    FOSVOS_REQUIRE((flags & ~(unsigned)(FOSVOS_CONV_RELU | FOSVOS_CONV_OUT_F32)) == 0, FOSVOS_E_ARG,
+                   "conv2d_fwd: unknown flags 0x%x", flags);
+    const bool f32 = flags & FOSVOS_CONV_OUT_F32;
+    FOSVOS_REQUIRE(!(f32 && addend), FOSVOS_E_SHAPE, "conv2d_fwd: fp32 output with a residual operand");
+    const int P = k / 2, Ho = (H + 2 * P - k) / stride + 1, Wo = (W + 2 * P - k) / stride + 1;
+    const int Cop = roundup(Co, 8), cic = roundup(Ci, 8) / 8;
+    FOSVOS_REQUIRE((int64_t)N * H * W * cic < (int64_t)1 << 31 && (int64_t)N * Ho * Wo * Cop < (int64_t)1 << 34, FOSVOS_E_ARG,
+                   "conv2d_fwd: tensor too large for 32-bit tap offsets");
+    FOSVOS_ENTER(device);
+    const int64_t npix = (int64_t)N * Ho * Wo;
+    const ConvLaunch L = plan_conv2d(npix, Cop);
+    const dim3 grid((unsigned)cdiv(npix, L.threads), (unsigned)cdiv(Cop, L.cob));
+    const int relu = (flags & FOSVOS_CONV_RELU) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const uint4 *xv = reinterpret_cast<const uint4 *>(x), *av = reinterpret_cast<const uint4 *>(addend);
+#define FOSVOS_ARGS L, grid, st, xv, w_packed, bias, av, y, N, H, W, Ho, Wo, cic, Cop, relu
+    if (k == 3 && stride == 1) {
+        if (f32) launch_conv2d<3, 1, true>(FOSVOS_ARGS);
+        else launch_conv2d<3, 1, false>(FOSVOS_ARGS);
+    } else if (k == 3) {
+        FOSVOS_REQUIRE(!f32, FOSVOS_E_SHAPE, "conv2d_fwd: fp32 output only for 3x3 stride 1");
+        launch_conv2d<3, 2, false>(FOSVOS_ARGS);
+    } else if (stride == 1) {
+        FOSVOS_REQUIRE(!f32, FOSVOS_E_SHAPE, "conv2d_fwd: fp32 output only for 3x3 stride 1");
+        launch_conv2d<1, 1, false>(FOSVOS_ARGS);
+    } else {
+        FOSVOS_REQUIRE(!f32, FOSVOS_E_SHAPE, "conv2d_fwd: fp32 output only for 3x3 stride 1");
+        launch_conv2d<1, 2, false>(FOSVOS_ARGS);
+    }
+#undef FOSVOS_ARGS
+    FOSVOS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t fosvos_conv7x7_packed_elems(int out_ch) {
+    return out_ch > 0 ? (size_t)147 * roundup(out_ch, 8) + 64 : 0;
+}
+
+extern "C" int fosvos_pack_conv7x7_bn(const float *w_oihw, int Co, const float *bn_weight, const float *bn_bias,
+                                      const float *bn_mean, const float *bn_var, float eps, float *w_packed,
+                                      float *bias_out, int device, void *stream) {
+    FOSVOS_REQUIRE(w_oihw && w_packed && bias_out && Co > 0, FOSVOS_E_ARG, "pack_conv7x7_bn: bad argument");
+    FOSVOS_REQUIRE(!bn_weight || (bn_bias && bn_mean && bn_var), FOSVOS_E_ARG, "pack_conv7x7_bn: partial BatchNorm");
+    FOSVOS_ENTER(device);
+    const int Cop = roundup(Co, 8), total = (int)fosvos_conv7x7_packed_elems(Co);
+    const int bias_len = (int)fosvos_conv2d_bias_elems(Co);
+    const int n = std::max(total, bias_len);
+    hipLaunchKernelGGL(k_pack_conv7x7_bn, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, Co,
+                       bn_weight, bn_bias, bn_mean, bn_var, eps, w_packed, bias_out, Cop, total, bias_len);
+    FOSVOS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fosvos_conv7x7s2_first_fwd(const float *frame, const float *w_packed, const float *bias, uint16_t *y, int N,
+                                          int H, int W, int Co, unsigned flags, int device, void *stream) {
+    FOSVOS_REQUIRE(frame && w_packed && bias && y, FOSVOS_E_ARG, "conv7x7s2_first_fwd: null pointer");
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && Co > 0, FOSVOS_E_ARG, "conv7x7s2_first_fwd: N=%d H=%d W=%d Co=%d", N, H, W, Co);
+    FOSVOS_REQUIRE((flags & ~(unsigned)FOSVOS_CONV_RELU) == 0, FOSVOS_E_ARG, "conv7x7s2_first_fwd: flags 0x%x", flags);
+    FOSVOS_ENTER(device);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, Cop = roundup(Co, 8);
+    const int64_t npix = (int64_t)N * Ho * Wo;
+    ConvLaunch L = plan_conv2d(npix, Cop);
+    const dim3 grid((unsigned)cdiv(npix, L.threads), (unsigned)cdiv(Cop, L.cob));
+    const int relu = (flags & FOSVOS_CONV_RELU) ? 1 : 0;
+    uint4 *yv = reinterpret_cast<uint4 *>(y);
+#define FOSVOS_GO(COB)                                                                                                 \
+    hipLaunchKernelGGL(k_conv7x7s2_first<COB>, grid, dim3(L.threads), 0, (hipStream_t)stream, frame, w_packed, bias, yv, N, \
+                       H, W, Ho, Wo, Cop, relu)
+    switch (L.cob) {
+        case 64: FOSVOS_GO(64); break;
+        case 32: FOSVOS_GO(32); break;
+        case 16: FOSVOS_GO(16); break;
+        default: FOSVOS_GO(8); break;
+    }
+#undef FOSVOS_GO
+    FOSVOS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fosvos_maxpool3x3s2_fwd(const uint16_t *x, uint16_t *y, int N, int H, int W, int C, int device,
+                                       void *stream) {
+    FOSVOS_REQUIRE(x && y, FOSVOS_E_ARG, "maxpool3x3s2_fwd: null pointer");
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, FOSVOS_E_ARG, "maxpool3x3s2_fwd: N=%d H=%d W=%d C=%d", N, H,
+                   W, C);
+    FOSVOS_ENTER(device);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(k_maxpool3x3s2, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4 *>(x), reinterpret_cast<uint4 *>(y), N, H, W, Ho, Wo, C / 8);
+    FOSVOS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fosvos_deconv_head_fwd(const float *const side[4], const int hs[4], const int ws[4], const int stride[4],
+                                      const float *const filt[4], const float *const filt1[4], const float *dsn_w,
+                                      const float *dsn_b, const float *fuse_b, float *fused, float *const side_out[4],
+                                      int N, int H, int W, int device, void *stream) {
+    FOSVOS_REQUIRE(side && hs && ws && stride && filt && fuse_b && fused, FOSVOS_E_ARG, "deconv_head_fwd: null pointer");
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && N < 65536, FOSVOS_E_ARG, "deconv_head_fwd: N=%d H=%d W=%d", N, H, W);
+    DeconvHeadArgs g;
+    const bool so = side_out && side_out[0];
+    for (int s = 0; s < 4; ++s) {
+        FOSVOS_REQUIRE(side[s] && filt[s], FOSVOS_E_ARG, "deconv_head_fwd: null side/filter pointer at scale %d", s);
+        FOSVOS_REQUIRE(hs[s] > 0 && ws[s] > 0 && stride[s] > 0, FOSVOS_E_ARG, "deconv_head_fwd: scale %d is %dx%d stride %d",
+                       s, hs[s], ws[s], stride[s]);
+        const int dh = (hs[s] + 1) * stride[s], dw = (ws[s] + 1) * stride[s];  // (h-1) f + 2f
+        FOSVOS_REQUIRE(dh >= H && dw >= W, FOSVOS_E_ARG,
+                       "deconv_head_fwd: scale %d upsamples to %dx%d, smaller than the %dx%d frame", s, dh, dw, H, W);
+        if (so)
+            FOSVOS_REQUIRE(side_out[s] && filt1 && filt1[s] && dsn_w && dsn_b, FOSVOS_E_ARG,
+                           "deconv_head_fwd: side outputs need side_out[%d], filt1, dsn_w, dsn_b", s);
+        g.side[s] = side[s];
+        g.filt[s] = filt[s];
+        g.filt1[s] = so ? filt1[s] : nullptr;
+        g.side_out[s] = so ? side_out[s] : nullptr;
+        g.hs[s] = hs[s];
+        g.ws[s] = ws[s];
+        g.f[s] = stride[s];
+        g.top[s] = (dh - H) / 2;  // the reference's centre crop drops floor(d/2) leading rows / columns
+        g.left[s] = (dw - W) / 2;
+    }
+    g.fused = fused;
+    g.dsn_w = dsn_w;
+    g.dsn_b = dsn_b;
+    g.fuse_b = fuse_b;
+    g.N = N;
+    g.H = H;
+    g.W = W;
+    g.with_side_out = so ? 1 : 0;
+    FOSVOS_ENTER(device);
+    hipLaunchKernelGGL(k_deconv_head, dim3((unsigned)cdiv(W, 64), (unsigned)cdiv(H, 4), (unsigned)N), dim3(64, 4), 0,
+                       (hipStream_t)stream, g);
+    FOSVOS_LAUNCH_CHECK();
+    return 0;
+}

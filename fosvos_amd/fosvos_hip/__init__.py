@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 CONV_RELU = 1
 CONV_OUT_F32 = 2
 
@@ -98,6 +98,21 @@ SIGNATURES = {
                                  c_int, c_void_p]),
     "fosvos_cbce_workspace_bytes": (c_size_t, [c_int64]),
     "fosvos_sgd_momentum_step": (c_int, [c_void_p, c_int, c_int64, c_float, c_int, c_int, c_void_p]),
+    "fosvos_conv2d_packed_dwords": (c_size_t, [c_int, c_int, c_int]),
+    "fosvos_conv2d_bias_elems": (c_size_t, [c_int]),
+    "fosvos_pack_conv2d_bn": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_float, c_void_p, c_void_p, c_int, c_void_p]),
+    "fosvos_conv2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_uint, c_int, c_void_p]),
+    "fosvos_conv7x7_packed_elems": (c_size_t, [c_int]),
+    "fosvos_pack_conv7x7_bn": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                       c_void_p, c_int, c_void_p]),
+    "fosvos_conv7x7s2_first_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_uint,
+                                           c_int, c_void_p]),
+    "fosvos_maxpool3x3s2_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fosvos_deconv_head_fwd": (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                                       POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p,
+                                       POINTER(c_void_p), c_int, c_int, c_int, c_int, c_void_p]),
     "fosvos_vgg_arena_bytes": (c_size_t, [c_int, c_int, c_int]),
     "fosvos_vgg_forward": (c_int, [POINTER(VggWeights), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                    POINTER(c_void_p), c_int, c_void_p]),

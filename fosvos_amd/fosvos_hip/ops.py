@@ -458,3 +458,153 @@ def cbce_loss(logits: torch.Tensor, label: torch.Tensor, size_average: bool = Tr
                              float(grad_scale), loss.data_ptr(), _p(grad), ws, wsn, dev, st), "cbce_loss")
     _pe(t0, "cbce_loss", 0.0, logits.numel() * (16 if want_grad else 12))
     return loss, grad
+
+
+# ------------------------------------------------------------------------------------------ thin-channel ResNet path
+def conv_out_size(h: int, k: int, stride: int) -> int:
+    return (h + 2 * (k // 2) - k) // stride + 1
+
+
+def pack_conv2d_bn(w: torch.Tensor, conv_bias: Optional[torch.Tensor] = None, bn: Optional[Sequence] = None):
+    """w: fp32 OIHW [Co,Ci,k,k] (k = 1 or 3); bn = (weight, bias, running_mean, running_var, eps) of the eval-mode
+    BatchNorm2d that follows the conv, or None.  Returns (packed int32 words, folded fp32 bias)."""
+    _need(w, _F32, "pack_conv2d_bn weight")
+    co, ci, k, k2 = w.shape
+    if k != k2:
+        raise ValueError("pack_conv2d_bn: square kernels only")
+    L = lib()
+    packed = torch.empty((L.fosvos_conv2d_packed_dwords(co, ci, k),), dtype=torch.int32, device=w.device)
+    bias = torch.empty((L.fosvos_conv2d_bias_elems(co),), dtype=_F32, device=w.device)
+    bnp = [None] * 4
+    eps = 0.0
+    if bn is not None:
+        for t in bn[:4]:
+            _need(t, _F32, "pack_conv2d_bn BatchNorm tensor")
+            if t.numel() != co:
+                raise ValueError("pack_conv2d_bn: BatchNorm size != out channels")
+        bnp = [t.data_ptr() for t in bn[:4]]
+        eps = float(bn[4])
+    if conv_bias is not None:
+        _need(conv_bias, _F32, "pack_conv2d_bn conv bias")
+    dev, st = _ctx(w)
+    check(L.fosvos_pack_conv2d_bn(w.data_ptr(), co, ci, k, _p(conv_bias), bnp[0], bnp[1], bnp[2], bnp[3], eps,
+                                  packed.data_ptr(), bias.data_ptr(), dev, st), "pack_conv2d_bn")
+    return packed, bias
+
+
+def conv2d_fwd(x: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, ci: int, co: int, k: int, stride: int = 1,
+               relu: bool = False, addend: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+    """x: bf16 NHWC [N,H,W,ru8(ci)] -> bf16 (or fp32) NHWC [N,Ho,Wo,ru8(co)] = act(conv + bias + addend)."""
+    _need(x, _BF16, "conv2d_fwd x")
+    _need(packed, torch.int32, "conv2d_fwd packed weights"); _need(bias, _F32, "conv2d_fwd bias")
+    n, h, w, cp = x.shape
+    L = lib()
+    if cp != _ru(ci, 8):
+        raise ValueError(f"conv2d_fwd: x has {cp} channels, expected {_ru(ci, 8)} (ci={ci} padded to 8)")
+    if packed.numel() != L.fosvos_conv2d_packed_dwords(co, ci, k) or bias.numel() != L.fosvos_conv2d_bias_elems(co):
+        raise ValueError("conv2d_fwd: packed image / bias size does not match (co, ci, k)")
+    ho, wo = conv_out_size(h, k, stride), conv_out_size(w, k, stride)
+    y = torch.empty((n, ho, wo, _ru(co, 8)), dtype=_F32 if out_f32 else _BF16, device=x.device)
+    if addend is not None:
+        _need(addend, _BF16, "conv2d_fwd addend")
+        if addend.shape != y.shape:
+            raise ValueError(f"conv2d_fwd: addend {tuple(addend.shape)} vs output {tuple(y.shape)}")
+    flags = (CONV_RELU if relu else 0) | (CONV_OUT_F32 if out_f32 else 0)
+    dev, st = _ctx(x)
+    t0 = _pb()
+    check(L.fosvos_conv2d_fwd(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), _p(addend), y.data_ptr(), n, h, w, ci, co,
+                              k, stride, flags, dev, st), "conv2d_fwd")
+    _pe(t0, f"conv{k}x{k}s{stride}", 2.0 * n * ho * wo * k * k * ci * co,
+        2 * x.numel() + y.numel() * y.element_size() + (2 * addend.numel() if addend is not None else 0))
+    return y
+
+
+def pack_conv7x7_bn(w: torch.Tensor, bn: Optional[Sequence] = None):
+    _need(w, _F32, "pack_conv7x7_bn weight")
+    co, ci, k, k2 = w.shape
+    if (ci, k, k2) != (3, 7, 7):
+        raise ValueError(f"pack_conv7x7_bn: expected [Co,3,7,7], got {tuple(w.shape)}")
+    L = lib()
+    packed = torch.empty((L.fosvos_conv7x7_packed_elems(co),), dtype=_F32, device=w.device)
+    bias = torch.empty((L.fosvos_conv2d_bias_elems(co),), dtype=_F32, device=w.device)
+    bnp = [None] * 4
+    eps = 0.0
+    if bn is not None:
+        for t in bn[:4]:
+            _need(t, _F32, "pack_conv7x7_bn BatchNorm tensor")
+        bnp = [t.data_ptr() for t in bn[:4]]
+        eps = float(bn[4])
+    dev, st = _ctx(w)
+    check(L.fosvos_pack_conv7x7_bn(w.data_ptr(), co, bnp[0], bnp[1], bnp[2], bnp[3], eps, packed.data_ptr(),
+                                   bias.data_ptr(), dev, st), "pack_conv7x7_bn")
+    return packed, bias
+
+
+def conv7x7s2_first_fwd(frame: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, co: int,
+                        relu: bool = True) -> torch.Tensor:
+    """frame: fp32 NCHW [N,3,H,W] -> bf16 NHWC [N,(H-1)//2+1,(W-1)//2+1,ru8(co)]."""
+    _need(frame, _F32, "conv7x7s2_first_fwd frame")
+    _need(packed, _F32, "conv7x7s2_first_fwd packed weights"); _need(bias, _F32, "conv7x7s2_first_fwd bias")
+    n, c, h, w = frame.shape
+    L = lib()
+    if c != 3:
+        raise ValueError("conv7x7s2_first_fwd: 3-channel frames only")
+    if packed.numel() != L.fosvos_conv7x7_packed_elems(co) or bias.numel() != L.fosvos_conv2d_bias_elems(co):
+        raise ValueError("conv7x7s2_first_fwd: packed image / bias size does not match co")
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty((n, ho, wo, _ru(co, 8)), dtype=_BF16, device=frame.device)
+    dev, st = _ctx(frame)
+    t0 = _pb()
+    check(L.fosvos_conv7x7s2_first_fwd(frame.data_ptr(), packed.data_ptr(), bias.data_ptr(), y.data_ptr(), n, h, w, co,
+                                       CONV_RELU if relu else 0, dev, st), "conv7x7s2_first_fwd")
+    _pe(t0, "conv7x7s2_first", 2.0 * n * ho * wo * 147 * co, 4 * frame.numel() + 2 * y.numel())
+    return y
+
+
+def maxpool3x3s2_fwd(x: torch.Tensor) -> torch.Tensor:
+    _need(x, _BF16, "maxpool3x3s2_fwd")
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=_BF16, device=x.device)
+    dev, st = _ctx(x)
+    t0 = _pb()
+    check(lib().fosvos_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), n, h, w, c, dev, st), "maxpool3x3s2_fwd")
+    _pe(t0, "maxpool3x3s2", 0.0, 2 * (x.numel() + y.numel()))
+    return y
+
+
+def deconv_head_fwd(side: Sequence[torch.Tensor], strides: Sequence[int], filt: Sequence[torch.Tensor],
+                    filt1: Optional[Sequence[torch.Tensor]], dsn_w: Optional[torch.Tensor],
+                    dsn_b: Optional[torch.Tensor], fuse_b: torch.Tensor, H: int, W: int, with_side_out: bool = True):
+    """side[s]: fp32 NHWC [N,hs,ws,16]; filt[s]: [2f,2f,16] (upscale filter contracted with the fuse weights);
+    filt1[s]: [2f,2f]; dsn_w [4,16]; dsn_b [4]; fuse_b [1].  Returns (fused [N,1,H,W], [4 side outputs] or None)."""
+    n = side[0].shape[0]
+    for s in range(4):
+        _need(side[s], _F32, "deconv_head_fwd side"); _need(filt[s], _F32, "deconv_head_fwd filt")
+        k = 2 * int(strides[s])
+        if side[s].shape[3] != 16 or tuple(filt[s].shape) != (k, k, 16):
+            raise ValueError("deconv_head_fwd: side/filter shape")
+    _need(fuse_b, _F32, "deconv_head_fwd fuse_b")
+    dev_t = side[0].device
+    fused = torch.empty((n, 1, H, W), dtype=_F32, device=dev_t)
+    outs = None
+    so_ptrs = [None] * 4
+    f1_ptrs = [None] * 4
+    if with_side_out:
+        outs = [torch.empty((n, 1, H, W), dtype=_F32, device=dev_t) for _ in range(4)]
+        so_ptrs = [o.data_ptr() for o in outs]
+        for s in range(4):
+            _need(filt1[s], _F32, "deconv_head_fwd filt1")
+            if tuple(filt1[s].shape) != (2 * int(strides[s]),) * 2:
+                raise ValueError("deconv_head_fwd: filt1 shape")
+        f1_ptrs = [f.data_ptr() for f in filt1]
+        _need(dsn_w, _F32, "deconv_head_fwd dsn_w"); _need(dsn_b, _F32, "deconv_head_fwd dsn_b")
+    dev, st = _ctx(side[0])
+    t0 = _pb()
+    check(lib().fosvos_deconv_head_fwd(ptr_array4([t.data_ptr() for t in side]), int_array4([t.shape[1] for t in side]),
+                                       int_array4([t.shape[2] for t in side]), int_array4([int(f) for f in strides]),
+                                       ptr_array4([t.data_ptr() for t in filt]), ptr_array4(f1_ptrs),
+                                       _p(dsn_w) if with_side_out else None, _p(dsn_b) if with_side_out else None,
+                                       fuse_b.data_ptr(), fused.data_ptr(), ptr_array4(so_ptrs), n, H, W, dev, st),
+          "deconv_head_fwd")
+    _pe(t0, "deconv_head_fwd", 2.0 * n * H * W * 256, 4 * (sum(t.numel() for t in side) + n * H * W * (5 if with_side_out else 1)))
+    return fused, outs

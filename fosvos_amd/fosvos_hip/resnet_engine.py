@@ -1,0 +1,133 @@
+"""Layer loop of the OSVOS_RESNET inference path over the C ABI: pack (BatchNorm folded) once per
+weight version, then one kernel per conv - residual add and ReLU included - plus the pool and the head.
+
+The walk is driven by the module tree, not by a version table: any trunk made of blocks with conv1/bn1/conv2/bn2
+[/conv3/bn3] and an optional ``downsample`` Sequential(conv, bn) runs, which covers BasicBlock, Bottleneck and the
+BasicBlockDummy nets of src/prune.py whatever their (pruned) channel counts.  Nothing here computes on the CPU and
+nothing imports the oracle; a module the kernels cannot express raises.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class _Conv:
+    """One packed conv (+ folded BatchNorm): what ops.conv2d_fwd needs."""
+    __slots__ = ("packed", "bias", "ci", "co", "k", "stride")
+
+    def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], what: str) -> None:
+        k = conv.kernel_size[0]
+        if (conv.kernel_size not in ((1, 1), (3, 3)) or conv.stride not in ((1, 1), (2, 2)) or conv.dilation != (1, 1)
+                or conv.groups != 1 or conv.padding != (k // 2, k // 2)):
+            raise NotImplementedError(f"{what}: {conv} - the HIP path has k in (1, 3), stride in (1, 2), padding k // 2")
+        if bn is not None and (not bn.track_running_stats or bn.running_mean is None or not bn.affine):
+            raise NotImplementedError(f"{what}: BatchNorm without affine running statistics cannot be folded")
+        self.ci, self.co, self.k, self.stride = conv.in_channels, conv.out_channels, k, conv.stride[0]
+        bnp = None if bn is None else (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+        self.packed, self.bias = ops.pack_conv2d_bn(conv.weight.detach(), None if conv.bias is None else conv.bias.detach(),
+                                                    bnp)
+
+    def __call__(self, x: torch.Tensor, relu: bool, addend: Optional[torch.Tensor] = None,
+                 out_f32: bool = False) -> torch.Tensor:
+        return ops.conv2d_fwd(x, self.packed, self.bias, self.ci, self.co, self.k, self.stride, relu, addend, out_f32)
+
+
+class _Block:
+    __slots__ = ("convs", "down")
+
+    def __init__(self, blk: nn.Module, what: str) -> None:
+        pairs = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
+        if hasattr(blk, "conv3"):
+            pairs.append((blk.conv3, blk.bn3))
+        self.convs = [_Conv(c, b, f"{what}.conv{i + 1}") for i, (c, b) in enumerate(pairs)]
+        self.down = None
+        if blk.downsample is not None:
+            self.down = _Conv(blk.downsample[0], blk.downsample[1], f"{what}.downsample")
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        res = x if self.down is None else self.down(x, relu=False)
+        y = x
+        for c in self.convs[:-1]:
+            y = c(y, relu=True)
+        return self.convs[-1](y, relu=True, addend=res)  # relu(bn(conv(y)) + residual)
+
+
+class ResnetPlan:
+    """Device-side images of one net's weights; rebuilt when any parameter or buffer was written or moved."""
+
+    def __init__(self) -> None:
+        self.signature = None
+
+    @staticmethod
+    def _signature(net: nn.Module):
+        return tuple((t.data_ptr(), t._version) for t in list(net.parameters()) + list(net.buffers()))
+
+    def refresh(self, net: nn.Module) -> None:
+        sig = self._signature(net)
+        if sig == self.signature:
+            return
+        conv1, bn1, _relu, pool = net.layer_base[0], net.layer_base[1], net.layer_base[2], net.layer_base[3]
+        if ((conv1.kernel_size, conv1.stride, conv1.padding, conv1.in_channels) != ((7, 7), (2, 2), (3, 3), 3)
+                or conv1.bias is not None):
+            raise NotImplementedError(f"layer_base conv {conv1}: the HIP path has the 7x7 stride-2 conv on 3-channel frames")
+        if (pool.kernel_size, pool.stride, pool.padding, pool.ceil_mode) != (3, 2, 1, False):
+            raise NotImplementedError(f"layer_base pool {pool}: the HIP path has MaxPool2d(3, 2, 1)")
+        self.c0 = conv1.out_channels
+        self.first = ops.pack_conv7x7_bn(conv1.weight.detach(),
+                                         (bn1.weight.detach(), bn1.bias.detach(), bn1.running_mean, bn1.running_var, bn1.eps))
+        self.stages: List[List[_Block]] = [[_Block(b, f"layer_stages.{i}.{j}") for j, b in enumerate(stage)]
+                                           for i, stage in enumerate(net.layer_stages)]
+        if len(self.stages) != 4:
+            raise NotImplementedError("the side-output head takes exactly four stages")
+        self.side = [_Conv(m, None, f"side_prep.{i}") for i, m in enumerate(net.side_prep)]
+        fuse_w = net.layer_fuse.weight.detach()
+        if tuple(fuse_w.shape) != (1, 64, 1, 1) or any(s.co != 16 for s in self.side):
+            raise NotImplementedError("the head kernel is built for 16-channel side maps and one output channel")
+        self.strides, self.filt, self.filt1 = [], [], []
+        for s in range(4):
+            up, up1 = net.upscale_side_prep[s], net.upscale_score_dsn[s]
+            f = up.stride[0]
+            for m in (up, up1):
+                if m.kernel_size != (2 * f, 2 * f) or m.stride != (f, f) or m.padding != (0, 0) or m.bias is not None:
+                    raise NotImplementedError(f"{m}: the head kernel has kernel = 2 x stride, no padding, no bias")
+            if tuple(up.weight.shape[:2]) != (16, 16) or tuple(up1.weight.shape[:2]) != (1, 1):
+                raise NotImplementedError("upscale layers must be 16 -> 16 and 1 -> 1")
+            # transposed conv and 1x1 fuse are both linear: contract them into one [k][k][16] filter per scale
+            self.filt.append(torch.einsum("o,iokl->kli", fuse_w[0, 16 * s:16 * s + 16, 0, 0], up.weight.detach()).contiguous())
+            self.filt1.append(up1.weight.detach()[0, 0].contiguous())
+            self.strides.append(f)
+        self.dsn_w = torch.cat([m.weight.detach().reshape(1, 16) for m in net.score_dsn]).contiguous()
+        self.dsn_b = torch.cat([m.bias.detach().reshape(1) for m in net.score_dsn]).contiguous()
+        self.fuse_b = net.layer_fuse.bias.detach().reshape(1).contiguous()
+        self.signature = sig
+
+
+def forward(net: nn.Module, plan: ResnetPlan, x: torch.Tensor) -> List[torch.Tensor]:
+    """[4 side outputs, fused], each [N,1,H,W] fp32 logits (src/networks/osvos_resnet.py:42-68)."""
+    if net.training:
+        raise RuntimeError("OSVOS_RESNET runs eval-mode inference on the HIP path (BatchNorm folded from its running "
+                           "statistics); training-mode forward/backward is not built - call net.eval()")
+    if not x.is_cuda:
+        raise RuntimeError("OSVOS_RESNET.forward: the input must live on the GPU (the HIP path has no CPU fallback)")
+    x = x.detach().contiguous().float()
+    with torch.no_grad():
+        plan.refresh(net)
+        n, _c, h, w = x.shape
+        y = ops.conv7x7s2_first_fwd(x, plan.first[0], plan.first[1], plan.c0, relu=True)
+        y = ops.maxpool3x3s2_fwd(y)
+        sides = []
+        for blocks, side in zip(plan.stages, plan.side):
+            for blk in blocks:
+                y = blk(y)
+            if y.shape[3] != (side.ci + 7) // 8 * 8 or blocks[-1].convs[-1].co != side.ci:
+                raise RuntimeError(f"side_prep expects {side.ci} input channels, the stage produces "
+                                   f"{blocks[-1].convs[-1].co}")
+            sides.append(side(y, relu=False, out_f32=True))
+        fused, outs = ops.deconv_head_fwd(sides, plan.strides, plan.filt, plan.filt1, plan.dsn_w, plan.dsn_b, plan.fuse_b,
+                                          h, w, with_side_out=True)
+    return outs + [fused]

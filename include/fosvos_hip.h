@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 7
+#define FOSVOS_ABI_VERSION 8
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -207,6 +207,53 @@ typedef struct fosvos_sgd_entry {
 } fosvos_sgd_entry;
 int fosvos_sgd_momentum_step(const fosvos_sgd_entry *table, int n_tensors, int64_t max_numel, float momentum,
                              int first_step, int device, void *stream);
+
+/* ---- thin-channel ResNet inference path (OSVOS_RESNET and the nets prune.py derives from it) ------
+ * Activations: bf16 NHWC [N,H,W,Cp] with Cp = channels rounded up to a multiple of 8, padded channels zero.
+ * Eval-mode BatchNorm is folded into the conv in front of it when the weights are packed:
+ *   s[o] = bn_weight[o] / sqrt(bn_var[o] + eps);  w'[o] = w[o] * s[o];  b'[o] = bn_bias[o] - bn_mean[o] * s[o]
+ *   (+ conv_bias[o] * s[o]; bn_* all NULL: no BatchNorm, b' = conv_bias or 0).
+ * Packed image: uint32 [Cip/8][k*k][4][Cop] (two bf16 input channels per word), fosvos_conv2d_packed_dwords words;
+ * folded bias: fosvos_conv2d_bias_elems floats (zero beyond Co).  The contraction runs on the vector ALU
+ * (v_dot2c_f32_bf16, fp32 accumulate) with any channel counts - these layers are too thin for the MFMA path.
+ * replaces: nn.Conv2d + nn.BatchNorm2d (+ residual add) + nn.ReLU of torchvision's BasicBlock / Bottleneck as wired by
+ *           src/networks/osvos_resnet.py:91-121,187-216, and the side_prep convs of :135. */
+size_t fosvos_conv2d_packed_dwords(int out_ch, int in_ch, int k);
+size_t fosvos_conv2d_bias_elems(int out_ch);
+int fosvos_pack_conv2d_bn(const float *w_oihw, int Co, int Ci, int k /* 1 or 3 */, const float *conv_bias,
+                          const float *bn_weight, const float *bn_bias, const float *bn_mean, const float *bn_var,
+                          float eps, uint32_t *w_packed, float *bias_out, int device, void *stream);
+/* y[N,Ho,Wo,Cop] = act(conv_k,stride,pad=k/2(x) + bias + addend); Ho = (H + 2 (k/2) - k) / stride + 1.
+ * addend: bf16 [N,Ho,Wo,Cop] or NULL (the residual branch).  flags: FOSVOS_CONV_RELU, FOSVOS_CONV_OUT_F32 (3x3
+ * stride 1 without addend only: the fp32 side maps the head reads). */
+int fosvos_conv2d_fwd(const uint16_t *x, const uint32_t *w_packed, const float *bias, const uint16_t *addend, void *y,
+                      int N, int H, int W, int Ci, int Co, int k, int stride, unsigned flags, int device, void *stream);
+/* First layer: 7x7 stride 2 pad 3 on the fp32 NCHW frame (3 channels) + folded BatchNorm (+ ReLU) -> bf16 NHWC
+ * [N,(H-1)/2+1,(W-1)/2+1,Cop].  Packed image: fp32 [49*3][Cop], fosvos_conv7x7_packed_elems floats.
+ * replaces: layer_base conv1 + bn1 + relu (src/networks/osvos_resnet.py:92-94). */
+size_t fosvos_conv7x7_packed_elems(int out_ch);
+int fosvos_pack_conv7x7_bn(const float *w_oihw, int Co, const float *bn_weight, const float *bn_bias,
+                           const float *bn_mean, const float *bn_var, float eps, float *w_packed, float *bias_out,
+                           int device, void *stream);
+int fosvos_conv7x7s2_first_fwd(const float *frame, const float *w_packed, const float *bias, uint16_t *y, int N, int H,
+                               int W, int Co, unsigned flags, int device, void *stream);
+/* MaxPool2d(kernel 3, stride 2, padding 1) on bf16 NHWC, C % 8 == 0: [N,H,W,C] -> [N,(H-1)/2+1,(W-1)/2+1,C].
+ * replaces: layer_base maxpool (src/networks/osvos_resnet.py:95). */
+int fosvos_maxpool3x3s2_fwd(const uint16_t *x, uint16_t *y, int N, int H, int W, int C, int device, void *stream);
+/* Side-output head with a free stride per scale (OSVOS_RESNET: 4, 8, 16, 32), forward only:
+ *   fused[n,0,Y,X]  = fuse_b + sum_s sum_c sum_taps filt[s][ky][kx][c] * side[s][n,i,j,c]
+ *   side_out[s][..] = sum_taps filt1[s][ky][kx] * (dsn_b[s] + sum_c dsn_w[s][c] * side[s][n,i,j,c])   (optional)
+ * over the taps of a transposed conv with kernel 2 f_s and stride f_s, centre-cropped to H x W as the reference
+ * does.  filt[s] = [2f][2f][16] is the upscale_side_prep[s] weight CONTRACTED with the fuse weights of scale s
+ * (G[ky][kx][ci] = sum_co fuse_w[16 s + co] * W[ci][co][ky][kx]; both maps are linear), so the full 16 -> 16
+ * transposed conv, the concat and the 1x1 fuse cost one filter.  filt1[s] = [2f][2f].
+ * replaces: upscale_side_prep, score_dsn, upscale_score_dsn, center_crop, torch.cat, layer_fuse
+ *           (src/networks/osvos_resnet.py:53-66). */
+int fosvos_deconv_head_fwd(const float *const side[4], const int hs[4], const int ws[4], const int stride[4],
+                           const float *const filt[4], const float *const filt1[4], const float *dsn_w /*[4][16]*/,
+                           const float *dsn_b /*[4]*/, const float *fuse_b /*[1]*/, float *fused,
+                           float *const side_out[4] /* all NULL or all set */, int N, int H, int W, int device,
+                           void *stream);
 
 /* ---- whole-network entry points ------------------------------------------------------------------
  * The reference drives ~60 torch.nn calls per forward from Python (src/networks/osvos_vgg.py:61-83) and
