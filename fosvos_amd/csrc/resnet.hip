@@ -83,11 +83,15 @@ __global__ void k_pack_conv7x7_bn(const float *__restrict__ w, int Co, const flo
 }
 
 // ------------------------------------------------------------------------------------------ k x k conv, stride S
-template <int KS, int S, int COB, bool OUT_F32>
-__global__ __launch_bounds__(256) void k_conv2d(const uint4 *__restrict__ x, const uint32_t *__restrict__ wp,
+// blockDim = (threads, KS): threadIdx.x picks the pixel, threadIdx.y a slice of the input-channel chunks (c = y, y + KS,
+// ...).  KS > 1 is for the deep layers, whose few thousand pixels cannot fill 1024 SIMDs on their own: the slices'
+// partial sums meet in LDS and slice 0 runs the epilogue.
+template <int KS, int S, int COB, bool OUT_F32, bool SLICED>
+__global__ __launch_bounds__(SLICED ? 512 : 256) void k_conv2d(const uint4 *__restrict__ x, const uint32_t *__restrict__ wp,
                                                 const float *__restrict__ bias, const uint4 *__restrict__ addend,
                                                 void *__restrict__ y, int N, int H, int W, int Ho, int Wo, int cic,
                                                 int Cop, int relu) {
+    extern __shared__ float red[];  // [slice - 1][COB][blockDim.x] when blockDim.y > 1
     constexpr int P = KS / 2, T = KS * KS;
     const int64_t npix = (int64_t)N * Ho * Wo;
     const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,6 +99,9 @@ __global__ __launch_bounds__(256) void k_conv2d(const uint4 *__restrict__ x, con
     const int64_t pc = live ? pix : npix - 1;
     const int ox = (int)(pc % Wo), oy = (int)((pc / Wo) % Ho), n = (int)(pc / ((int64_t)Wo * Ho));
     const int cb = blockIdx.y;
+    // (a wave never spans two slices - blockDim.x is a multiple of 64 - so the slice index is wave-uniform; saying so
+    // keeps the weight addresses scalar)
+    const int slice = SLICED ? __builtin_amdgcn_readfirstlane(threadIdx.y) : 0, slices = SLICED ? (int)blockDim.y : 1;
 
     int off[T];
     bool ok[T];
@@ -109,22 +116,52 @@ __global__ __launch_bounds__(256) void k_conv2d(const uint4 *__restrict__ x, con
     for (int j = 0; j < COB; ++j) acc[j] = 0.f;
 
     const uint32_t *wb = wp + cb * COB;
-    for (int c = 0; c < cic; ++c) {
-        uint4 a[T];
+    // SLICED launches run few waves per SIMD, so the next chunk's taps are fetched while this one is multiplied; the
+    // others hide the latency behind their neighbours and keep the registers (4 waves per SIMD instead of 2).
+    uint4 a[T];
+    if (SLICED) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            a[t] = x[off[t] + c];
-            if (!ok[t]) a[t] = make_uint4(0, 0, 0, 0);
+        for (int t = 0; t < T; ++t) a[t] = x[off[t] + slice];
+    }
+    for (int c = slice; c < cic; c += slices) {
+        uint4 an[T];
+        if (SLICED) {
+            const int cn = min(c + slices, cic - 1);
+#pragma unroll
+            for (int t = 0; t < T; ++t) an[t] = x[off[t] + cn];
+        } else {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                a[t] = x[off[t] + c];
+                if (!ok[t]) a[t] = make_uint4(0, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const uint32_t *wt = wb + (int64_t)((c * T + t) * 4) * Cop;  // uniform across the wave: scalar loads
-            const uint32_t av[4] = {a[t].x, a[t].y, a[t].z, a[t].w};
+            const uint4 at = (SLICED && !ok[t]) ? make_uint4(0, 0, 0, 0) : a[t];
+            const uint32_t av[4] = {at.x, at.y, at.z, at.w};
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
                 for (int j = 0; j < COB; ++j) acc[j] = dot2(av[p], wt[p * Cop + j], acc[j]);
         }
+        if (SLICED) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) a[t] = an[t];
+        }
+    }
+    if (SLICED) {
+        const int bx = blockDim.x;
+        if (slice > 0) {
+#pragma unroll
+            for (int j = 0; j < COB; ++j) red[((slice - 1) * COB + j) * bx + threadIdx.x] = acc[j];
+        }
+        __syncthreads();
+        if (slice > 0) return;
+        for (int q = 0; q < slices - 1; ++q)
+#pragma unroll
+            for (int j = 0; j < COB; ++j) acc[j] += red[(q * COB + j) * bx + threadIdx.x];
     }
     if (!live) return;
     const int cop8 = Cop >> 3;
@@ -256,14 +293,23 @@ struct DeconvHeadArgs {
     int N, H, W, with_side_out;
 };
 
+// A thread owns DH_PX pixels of one row, 64 columns apart: every stride divides 64, so they share the filter phase
+// (ky, kx) at every scale and the 4 taps x 16 channels of filter are fetched once per scale for all of them - the
+// filter rows (64 B per lane, all lanes different) are what the L1 path spends its time on, the side maps are read by
+// groups of f lanes at the same address.
+constexpr int DH_PX = 8;
+
 __global__ __launch_bounds__(256) void k_deconv_head(const DeconvHeadArgs g) {
-    const int X = blockIdx.x * 64 + threadIdx.x, Y = blockIdx.y * 4 + threadIdx.y, n = blockIdx.z;
-    if (X >= g.W || Y >= g.H) return;
-    float fused = g.fuse_b[0];
+    const int X0 = blockIdx.x * (64 * DH_PX) + threadIdx.x, Y = blockIdx.y * 4 + threadIdx.y, n = blockIdx.z;
+    if (Y >= g.H || X0 >= g.W) return;
+    float fused[DH_PX];
+    const float fb = g.fuse_b[0];
+#pragma unroll
+    for (int p = 0; p < DH_PX; ++p) fused[p] = fb;
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
-        const int f = g.f[s], k = 2 * f, hs = g.hs[s], ws = g.ws[s];
-        const int yy = Y + g.top[s], xx = X + g.left[s];
+        const int f = g.f[s], k = 2 * f, hs = g.hs[s], ws = g.ws[s], jstep = 64 / f;
+        const int yy = Y + g.top[s], xx = X0 + g.left[s];
         const int i0 = yy / f, ky0 = yy - i0 * f, j0 = xx / f, kx0 = xx - j0 * f;
         float dw[16];
         float db = 0.f;
@@ -272,47 +318,62 @@ __global__ __launch_bounds__(256) void k_deconv_head(const DeconvHeadArgs g) {
             for (int c = 0; c < 16; ++c) dw[c] = g.dsn_w[s * 16 + c];
             db = g.dsn_b[s];
         }
-        float so = 0.f;
+        float so[DH_PX];
+#pragma unroll
+        for (int p = 0; p < DH_PX; ++p) so[p] = 0.f;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int i = i0 - a, ky = ky0 + a * f;
             if (i < 0 || i >= hs) continue;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const int j = j0 - b, kx = kx0 + b * f;
-                if (j < 0 || j >= ws) continue;
-                const float4 *sp = reinterpret_cast<const float4 *>(g.side[s]) + (((int64_t)n * hs + i) * ws + j) * 4;
+                const int kx = kx0 + b * f;
                 const float4 *fp = reinterpret_cast<const float4 *>(g.filt[s]) + ((int64_t)ky * k + kx) * 4;
-                float d = db;
+                const float4 f0 = fp[0], f1 = fp[1], f2 = fp[2], f3 = fp[3];
+                const float w1 = g.with_side_out ? g.filt1[s][ky * k + kx] : 0.f;
+                const float4 *srow = reinterpret_cast<const float4 *>(g.side[s]) + ((int64_t)n * hs + i) * ws * 4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 sv = sp[q], fv = fp[q];
-                    fused = fmaf(sv.x, fv.x, fused);
-                    fused = fmaf(sv.y, fv.y, fused);
-                    fused = fmaf(sv.z, fv.z, fused);
-                    fused = fmaf(sv.w, fv.w, fused);
+                for (int p = 0; p < DH_PX; ++p) {
+                    const int j = j0 + p * jstep - b;
+                    if (X0 + 64 * p >= g.W || j < 0 || j >= ws) continue;
+                    const float4 *sp = srow + (int64_t)j * 4;
+                    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+                    float t = fused[p];
+                    t = fmaf(s0.x, f0.x, t); t = fmaf(s0.y, f0.y, t); t = fmaf(s0.z, f0.z, t); t = fmaf(s0.w, f0.w, t);
+                    t = fmaf(s1.x, f1.x, t); t = fmaf(s1.y, f1.y, t); t = fmaf(s1.z, f1.z, t); t = fmaf(s1.w, f1.w, t);
+                    t = fmaf(s2.x, f2.x, t); t = fmaf(s2.y, f2.y, t); t = fmaf(s2.z, f2.z, t); t = fmaf(s2.w, f2.w, t);
+                    t = fmaf(s3.x, f3.x, t); t = fmaf(s3.y, f3.y, t); t = fmaf(s3.z, f3.z, t); t = fmaf(s3.w, f3.w, t);
+                    fused[p] = t;
                     if (g.with_side_out) {
-                        d = fmaf(sv.x, dw[q * 4 + 0], d);
-                        d = fmaf(sv.y, dw[q * 4 + 1], d);
-                        d = fmaf(sv.z, dw[q * 4 + 2], d);
-                        d = fmaf(sv.w, dw[q * 4 + 3], d);
+                        float d = db;
+                        d = fmaf(s0.x, dw[0], d); d = fmaf(s0.y, dw[1], d); d = fmaf(s0.z, dw[2], d); d = fmaf(s0.w, dw[3], d);
+                        d = fmaf(s1.x, dw[4], d); d = fmaf(s1.y, dw[5], d); d = fmaf(s1.z, dw[6], d); d = fmaf(s1.w, dw[7], d);
+                        d = fmaf(s2.x, dw[8], d); d = fmaf(s2.y, dw[9], d); d = fmaf(s2.z, dw[10], d); d = fmaf(s2.w, dw[11], d);
+                        d = fmaf(s3.x, dw[12], d); d = fmaf(s3.y, dw[13], d); d = fmaf(s3.z, dw[14], d); d = fmaf(s3.w, dw[15], d);
+                        so[p] = fmaf(w1, d, so[p]);
                     }
                 }
-                if (g.with_side_out) so = fmaf(g.filt1[s][ky * k + kx], d, so);
             }
         }
-        if (g.with_side_out) g.side_out[s][((int64_t)n * g.H + Y) * g.W + X] = so;
+        if (g.with_side_out) {
+#pragma unroll
+            for (int p = 0; p < DH_PX; ++p)
+                if (X0 + 64 * p < g.W) g.side_out[s][((int64_t)n * g.H + Y) * g.W + X0 + 64 * p] = so[p];
+        }
     }
-    g.fused[((int64_t)n * g.H + Y) * g.W + X] = fused;
+#pragma unroll
+    for (int p = 0; p < DH_PX; ++p)
+        if (X0 + 64 * p < g.W) g.fused[((int64_t)n * g.H + Y) * g.W + X0 + 64 * p] = fused[p];
 }
 
 // ------------------------------------------------------------------------------------------ launch planning
 // Output-channel block of a launch: the widest of 64/32/16/8 that wastes at most an eighth of its lanes on channel
-// padding and still gives the chip 8 waves per CU; thin or deep layers fall back to narrower blocks (more waves).
+// padding and still gives the chip 2 waves per SIMD; thin or deep layers fall back to narrower blocks (more waves), and
+// when even 8-channel blocks leave SIMDs empty the input channels are split over up to 8 waves of a workgroup.
 struct ConvLaunch {
-    int cob, threads;
+    int cob, threads, slices;
 };
-ConvLaunch plan_conv2d(int64_t npix, int Cop) {
+ConvLaunch plan_conv2d(int64_t npix, int Cop, int cic) {
     const int cand[4] = {64, 32, 16, 8};
     int pick = 8;
     for (int q = 0; q < 4; ++q) {
@@ -322,20 +383,29 @@ ConvLaunch plan_conv2d(int64_t npix, int Cop) {
         if (cdiv(npix, 64) * nb >= 2048) break;
     }
     const int nb = (Cop + pick - 1) / pick;
-    return {pick, cdiv(npix, 256) * nb >= 1024 ? 256 : 64};
+    const int64_t waves = cdiv(npix, 64) * nb;
+    if (waves >= 2048 || cic < 2) return {pick, cdiv(npix, 256) * nb >= 1024 ? 256 : 64, 1};
+    int slices = 2;
+    while (slices < 8 && slices * 2 <= cic && waves * slices < 4096) slices *= 2;
+    return {pick, 64, slices};
 }
 
 template <int KS, int S, bool OUT_F32>
 void launch_conv2d(const ConvLaunch &L, dim3 grid, hipStream_t st, const uint4 *x, const uint32_t *wp, const float *bias,
                    const uint4 *addend, void *y, int N, int H, int W, int Ho, int Wo, int cic, int Cop, int relu) {
-#define FOSVOS_GO(COB)                                                                                                 \
-    hipLaunchKernelGGL((k_conv2d<KS, S, COB, OUT_F32>), grid, dim3(L.threads), 0, st, x, wp, bias, addend, y, N, H, W, Ho, \
-                       Wo, cic, Cop, relu)
+    const size_t lds = L.slices > 1 ? (size_t)(L.slices - 1) * L.cob * L.threads * sizeof(float) : 0;  // <= 7*64*64*4
+#define FOSVOS_GO(COB, SLICED)                                                                                          \
+    hipLaunchKernelGGL((k_conv2d<KS, S, COB, OUT_F32, SLICED>), grid, dim3(L.threads, L.slices), lds, st, x, wp, bias,      \
+                       addend, y, N, H, W, Ho, Wo, cic, Cop, relu)
+    if (L.slices > 1) {  // (only ever planned with 8-channel blocks)
+        FOSVOS_GO(8, true);
+        return;
+    }
     switch (L.cob) {
-        case 64: FOSVOS_GO(64); break;
-        case 32: FOSVOS_GO(32); break;
-        case 16: FOSVOS_GO(16); break;
-        default: FOSVOS_GO(8); break;
+        case 64: FOSVOS_GO(64, false); break;
+        case 32: FOSVOS_GO(32, false); break;
+        case 16: FOSVOS_GO(16, false); break;
+        default: FOSVOS_GO(8, false); break;
     }
 #undef FOSVOS_GO
 }
@@ -385,7 +455,7 @@ extern "C" int fosvos_conv2d_fwd(const uint16_t *x, const uint32_t *w_packed, co
                    "conv2d_fwd: tensor too large for 32-bit tap offsets");
     FOSVOS_ENTER(device);
     const int64_t npix = (int64_t)N * Ho * Wo;
-    const ConvLaunch L = plan_conv2d(npix, Cop);
+    const ConvLaunch L = plan_conv2d(npix, Cop, cic);
     const dim3 grid((unsigned)cdiv(npix, L.threads), (unsigned)cdiv(Cop, L.cob));
     const int relu = (flags & FOSVOS_CONV_RELU) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
@@ -436,7 +506,7 @@ extern "C" int fosvos_conv7x7s2_first_fwd(const float *frame, const float *w_pac
     FOSVOS_ENTER(device);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, Cop = roundup(Co, 8);
     const int64_t npix = (int64_t)N * Ho * Wo;
-    ConvLaunch L = plan_conv2d(npix, Cop);
+    ConvLaunch L = plan_conv2d(npix, Cop, 1);
     const dim3 grid((unsigned)cdiv(npix, L.threads), (unsigned)cdiv(Cop, L.cob));
     const int relu = (flags & FOSVOS_CONV_RELU) ? 1 : 0;
     uint4 *yv = reinterpret_cast<uint4 *>(y);
@@ -480,6 +550,8 @@ extern "C" int fosvos_deconv_head_fwd(const float *const side[4], const int hs[4
         FOSVOS_REQUIRE(side[s] && filt[s], FOSVOS_E_ARG, "deconv_head_fwd: null side/filter pointer at scale %d", s);
         FOSVOS_REQUIRE(hs[s] > 0 && ws[s] > 0 && stride[s] > 0, FOSVOS_E_ARG, "deconv_head_fwd: scale %d is %dx%d stride %d",
                        s, hs[s], ws[s], stride[s]);
+        FOSVOS_REQUIRE(64 % stride[s] == 0, FOSVOS_E_SHAPE, "deconv_head_fwd: stride %d of scale %d does not divide 64",
+                       stride[s], s);
         const int dh = (hs[s] + 1) * stride[s], dw = (ws[s] + 1) * stride[s];  // (h-1) f + 2f
         FOSVOS_REQUIRE(dh >= H && dw >= W, FOSVOS_E_ARG,
                        "deconv_head_fwd: scale %d upsamples to %dx%d, smaller than the %dx%d frame", s, dh, dw, H, W);
@@ -505,7 +577,7 @@ extern "C" int fosvos_deconv_head_fwd(const float *const side[4], const int hs[4
     g.W = W;
     g.with_side_out = so ? 1 : 0;
     FOSVOS_ENTER(device);
-    hipLaunchKernelGGL(k_deconv_head, dim3((unsigned)cdiv(W, 64), (unsigned)cdiv(H, 4), (unsigned)N), dim3(64, 4), 0,
+    hipLaunchKernelGGL(k_deconv_head, dim3((unsigned)cdiv(W, 64 * DH_PX), (unsigned)cdiv(H, 4), (unsigned)N), dim3(64, 4), 0,
                        (hipStream_t)stream, g);
     FOSVOS_LAUNCH_CHECK();
     return 0;

@@ -65,8 +65,9 @@ class OpProfiler:
     the stream every kernel here is launched on).  Off by default: bench.py turns it on for a few
     iterations AFTER its timed region to obtain per-kernel durations for the roofline line."""
 
-    def __init__(self) -> None:
+    def __init__(self, detail: bool = False) -> None:
         self.records = []  # (name, flops, bytes, start_event, end_event)
+        self.detail = detail  # per-shape names for the generic conv (tools/resnet_infer_bench.py --detail)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -514,7 +515,8 @@ def conv2d_fwd(x: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, ci: in
     t0 = _pb()
     check(L.fosvos_conv2d_fwd(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), _p(addend), y.data_ptr(), n, h, w, ci, co,
                               k, stride, flags, dev, st), "conv2d_fwd")
-    _pe(t0, f"conv{k}x{k}s{stride}", 2.0 * n * ho * wo * k * k * ci * co,
+    _pe(t0, f"conv{k}x{k}s{stride} {ci}->{co} @{ho}x{wo}" if _PROF is not None and _PROF.detail else f"conv{k}x{k}s{stride}",
+        2.0 * n * ho * wo * k * k * ci * co,
         2 * x.numel() + y.numel() * y.element_size() + (2 * addend.numel() if addend is not None else 0))
     return y
 
