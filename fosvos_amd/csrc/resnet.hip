@@ -582,3 +582,143 @@ extern "C" int fosvos_deconv_head_fwd(const float *const side[4], const int hs[4
     FOSVOS_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------ whole-network forward
+namespace {
+
+struct ActShape {
+    int h, w, c;  // c = real channels
+    size_t bytes(int N) const { return (size_t)N * h * w * roundup(c, 8) * sizeof(uint16_t); }
+};
+inline int conv_out(int h, int k, int stride) { return (h + 2 * (k / 2) - k) / stride + 1; }
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Arena: [first conv output][4 rotating activation slots of the largest block tensor][4 fp32 side maps]
+struct ResnetLayout {
+    size_t first_bytes, slot_bytes, side_off[4], side_bytes[4], total;
+    int hs[4], ws[4];
+};
+
+int resnet_layout(const fosvos_resnet_net *net, int N, int H, int W, ResnetLayout *L) {
+    FOSVOS_REQUIRE(net && net->blocks && net->first_w && net->first_b && net->first_co > 0, FOSVOS_E_ARG,
+                   "resnet: null net / blocks / first layer");
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0, FOSVOS_E_ARG, "resnet: N=%d H=%d W=%d", N, H, W);
+    ActShape a{(H - 1) / 2 + 1, (W - 1) / 2 + 1, net->first_co};
+    L->first_bytes = align256(a.bytes(N));
+    a.h = (a.h - 1) / 2 + 1;
+    a.w = (a.w - 1) / 2 + 1;
+    size_t slot = a.bytes(N);
+    int b = 0;
+    for (int s = 0; s < 4; ++s) {
+        FOSVOS_REQUIRE(net->blocks_per_stage[s] > 0, FOSVOS_E_ARG, "resnet: stage %d has no blocks", s);
+        for (int j = 0; j < net->blocks_per_stage[s]; ++j, ++b) {
+            const fosvos_resnet_block &blk = net->blocks[b];
+            FOSVOS_REQUIRE(blk.n_convs == 2 || blk.n_convs == 3, FOSVOS_E_ARG, "resnet: block %d has %d convs", b, blk.n_convs);
+            ActShape y = a;
+            for (int q = 0; q < blk.n_convs; ++q) {
+                const fosvos_conv2d_desc &c = blk.conv[q];
+                FOSVOS_REQUIRE(c.w_packed && c.bias && c.Ci == y.c, FOSVOS_E_SHAPE,
+                               "resnet: block %d conv %d takes %d channels, its input has %d", b, q + 1, c.Ci, y.c);
+                y = ActShape{conv_out(y.h, c.k, c.stride), conv_out(y.w, c.k, c.stride), c.Co};
+                slot = std::max(slot, y.bytes(N));
+            }
+            ActShape r = a;
+            if (blk.has_down) {
+                FOSVOS_REQUIRE(blk.down.w_packed && blk.down.bias && blk.down.Ci == a.c, FOSVOS_E_SHAPE,
+                               "resnet: block %d downsample takes %d channels, its input has %d", b, blk.down.Ci, a.c);
+                r = ActShape{conv_out(a.h, blk.down.k, blk.down.stride), conv_out(a.w, blk.down.k, blk.down.stride), blk.down.Co};
+                slot = std::max(slot, r.bytes(N));
+            }
+            FOSVOS_REQUIRE(r.h == y.h && r.w == y.w && r.c == y.c, FOSVOS_E_SHAPE,
+                           "resnet: block %d residual is %dx%dx%d, the conv branch %dx%dx%d", b, r.h, r.w, r.c, y.h, y.w, y.c);
+            a = y;
+        }
+        const fosvos_conv2d_desc &sp = net->side[s];
+        FOSVOS_REQUIRE(sp.w_packed && sp.bias && sp.Co == 16 && sp.k == 3 && sp.stride == 1, FOSVOS_E_SHAPE,
+                       "resnet: side_prep %d must be a 3x3 stride-1 conv to 16 channels", s);
+        FOSVOS_REQUIRE(sp.Ci == a.c, FOSVOS_E_SHAPE, "resnet: side_prep %d expects %d input channels, the stage produces %d", s,
+                       sp.Ci, a.c);
+        L->hs[s] = a.h;
+        L->ws[s] = a.w;
+        L->side_bytes[s] = align256((size_t)N * a.h * a.w * 16 * sizeof(float));
+    }
+    L->slot_bytes = align256(slot);
+    size_t off = L->first_bytes + 4 * L->slot_bytes;
+    for (int s = 0; s < 4; ++s) {
+        L->side_off[s] = off;
+        off += L->side_bytes[s];
+    }
+    L->total = off + 256;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t fosvos_resnet_arena_bytes(const fosvos_resnet_net *net, int N, int H, int W) {
+    ResnetLayout L;
+    return resnet_layout(net, N, H, W, &L) ? 0 : L.total;
+}
+
+extern "C" int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *frame, int N, int H, int W, void *arena,
+                                     size_t arena_bytes, float *fused, float *const side_out[4], int device,
+                                     void *stream) {
+    ResnetLayout L;
+    if (int rc = resnet_layout(net, N, H, W, &L)) return rc;
+    FOSVOS_REQUIRE(frame && arena && fused, FOSVOS_E_ARG, "resnet_forward: null pointer");
+    FOSVOS_REQUIRE(arena_bytes >= L.total, FOSVOS_E_WORKSPACE, "resnet_forward: arena of %zu bytes, %zu needed", arena_bytes,
+                   L.total);
+    char *base = reinterpret_cast<char *>(((uintptr_t)arena + 255) & ~(uintptr_t)255);
+    uint16_t *first = reinterpret_cast<uint16_t *>(base);
+    uint16_t *slot[4];
+    for (int q = 0; q < 4; ++q) slot[q] = reinterpret_cast<uint16_t *>(base + L.first_bytes + q * L.slot_bytes);
+    auto other = [](int a, int b, int c) {  // a slot that is none of a, b, c
+        for (int q = 0; q < 4; ++q)
+            if (q != a && q != b && q != c) return q;
+        return 0;
+    };
+
+    int h = (H - 1) / 2 + 1, w = (W - 1) / 2 + 1;
+    if (int rc = fosvos_conv7x7s2_first_fwd(frame, net->first_w, net->first_b, first, N, H, W, net->first_co, FOSVOS_CONV_RELU,
+                                            device, stream))
+        return rc;
+    if (int rc = fosvos_maxpool3x3s2_fwd(first, slot[0], N, h, w, roundup(net->first_co, 8), device, stream)) return rc;
+    h = (h - 1) / 2 + 1;
+    w = (w - 1) / 2 + 1;
+    int cur = 0, b = 0;
+    const float *side[4];
+    for (int s = 0; s < 4; ++s) {
+        for (int j = 0; j < net->blocks_per_stage[s]; ++j, ++b) {
+            const fosvos_resnet_block &blk = net->blocks[b];
+            int res = cur;
+            if (blk.has_down) {
+                res = other(cur, -1, -1);
+                if (int rc = fosvos_conv2d_fwd(slot[cur], blk.down.w_packed, blk.down.bias, nullptr, slot[res], N, h, w,
+                                               blk.down.Ci, blk.down.Co, blk.down.k, blk.down.stride, 0, device, stream))
+                    return rc;
+            }
+            int in = cur, ih = h, iw = w;
+            for (int q = 0; q < blk.n_convs; ++q) {
+                const fosvos_conv2d_desc &c = blk.conv[q];
+                const bool last = q == blk.n_convs - 1;
+                const int out = other(in, res, last ? -1 : cur);  // (the block input stays live until the residual is taken)
+                if (int rc = fosvos_conv2d_fwd(slot[in], c.w_packed, c.bias, last ? slot[res] : nullptr, slot[out], N, ih, iw,
+                                               c.Ci, c.Co, c.k, c.stride, FOSVOS_CONV_RELU, device, stream))
+                    return rc;
+                ih = conv_out(ih, c.k, c.stride);
+                iw = conv_out(iw, c.k, c.stride);
+                in = out;
+            }
+            cur = in;
+            h = ih;
+            w = iw;
+        }
+        float *sm = reinterpret_cast<float *>(base + L.side_off[s]);
+        const fosvos_conv2d_desc &sp = net->side[s];
+        if (int rc = fosvos_conv2d_fwd(slot[cur], sp.w_packed, sp.bias, nullptr, sm, N, h, w, sp.Ci, sp.Co, 3, 1,
+                                       FOSVOS_CONV_OUT_F32, device, stream))
+            return rc;
+        side[s] = sm;
+    }
+    return fosvos_deconv_head_fwd(side, L.hs, L.ws, net->stride, net->filt, net->filt1, net->dsn_w, net->dsn_b, net->fuse_b,
+                                  fused, side_out, N, H, W, device, stream);
+}

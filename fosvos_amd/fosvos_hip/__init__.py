@@ -52,6 +52,24 @@ class PackEntry(ctypes.Structure):
     _fields_ = [("w", c_void_p), ("w_fwd", c_void_p), ("w_dgrad", c_void_p), ("Co", c_int), ("Ci", c_int)]
 
 
+
+class Conv2dDesc(ctypes.Structure):
+    """fosvos_conv2d_desc."""
+    _fields_ = [("w_packed", c_void_p), ("bias", c_void_p), ("Ci", c_int), ("Co", c_int), ("k", c_int), ("stride", c_int)]
+
+
+class ResnetBlock(ctypes.Structure):
+    """fosvos_resnet_block."""
+    _fields_ = [("conv", Conv2dDesc * 3), ("n_convs", c_int), ("has_down", c_int), ("down", Conv2dDesc)]
+
+
+class ResnetNet(ctypes.Structure):
+    """fosvos_resnet_net (host struct; `blocks` points at a host array of ResnetBlock)."""
+    _fields_ = [("first_w", c_void_p), ("first_b", c_void_p), ("first_co", c_int), ("blocks_per_stage", c_int * 4),
+                ("blocks", POINTER(ResnetBlock)), ("side", Conv2dDesc * 4), ("filt", c_void_p * 4),
+                ("filt1", c_void_p * 4), ("stride", c_int * 4), ("dsn_w", c_void_p), ("dsn_b", c_void_p),
+                ("fuse_b", c_void_p)]
+
 # name -> (restype, argtypes); every entry point of include/fosvos_hip.h
 SIGNATURES = {
     "fosvos_abi_version": (c_int, []),
@@ -113,6 +131,9 @@ SIGNATURES = {
     "fosvos_deconv_head_fwd": (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                        POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p,
                                        POINTER(c_void_p), c_int, c_int, c_int, c_int, c_void_p]),
+    "fosvos_resnet_arena_bytes": (c_size_t, [POINTER(ResnetNet), c_int, c_int, c_int]),
+    "fosvos_resnet_forward": (c_int, [POINTER(ResnetNet), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
+                                      POINTER(c_void_p), c_int, c_void_p]),
     "fosvos_vgg_arena_bytes": (c_size_t, [c_int, c_int, c_int]),
     "fosvos_vgg_forward": (c_int, [POINTER(VggWeights), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                    POINTER(c_void_p), c_int, c_void_p]),

@@ -13,7 +13,9 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from . import ops
+import ctypes
+
+from . import Conv2dDesc, ResnetBlock, ResnetNet, check, lib, ops, ptr_array4
 
 
 class _Conv:
@@ -35,6 +37,9 @@ class _Conv:
     def __call__(self, x: torch.Tensor, relu: bool, addend: Optional[torch.Tensor] = None,
                  out_f32: bool = False) -> torch.Tensor:
         return ops.conv2d_fwd(x, self.packed, self.bias, self.ci, self.co, self.k, self.stride, relu, addend, out_f32)
+
+    def desc(self) -> Conv2dDesc:
+        return Conv2dDesc(self.packed.data_ptr(), self.bias.data_ptr(), self.ci, self.co, self.k, self.stride)
 
 
 class _Block:
@@ -104,17 +109,47 @@ class ResnetPlan:
         self.dsn_w = torch.cat([m.weight.detach().reshape(1, 16) for m in net.score_dsn]).contiguous()
         self.dsn_b = torch.cat([m.bias.detach().reshape(1) for m in net.score_dsn]).contiguous()
         self.fuse_b = net.layer_fuse.bias.detach().reshape(1).contiguous()
+        self._build_native()
         self.signature = sig
 
+    def _build_native(self) -> None:
+        """The host structs fosvos_resnet_forward walks (they point into the tensors this plan keeps alive)."""
+        flat = [b for stage in self.stages for b in stage]
+        self.c_blocks = (ResnetBlock * len(flat))()
+        for cb, b in zip(self.c_blocks, flat):
+            cb.n_convs = len(b.convs)
+            for q, c in enumerate(b.convs):
+                cb.conv[q] = c.desc()
+            cb.has_down = 0 if b.down is None else 1
+            if b.down is not None:
+                cb.down = b.down.desc()
+        net = ResnetNet()
+        net.first_w, net.first_b, net.first_co = self.first[0].data_ptr(), self.first[1].data_ptr(), self.c0
+        for s in range(4):
+            net.blocks_per_stage[s] = len(self.stages[s])
+            net.side[s] = self.side[s].desc()
+            net.filt[s], net.filt1[s], net.stride[s] = self.filt[s].data_ptr(), self.filt1[s].data_ptr(), self.strides[s]
+        net.blocks = ctypes.cast(self.c_blocks, ctypes.POINTER(ResnetBlock))
+        net.dsn_w, net.dsn_b, net.fuse_b = self.dsn_w.data_ptr(), self.dsn_b.data_ptr(), self.fuse_b.data_ptr()
+        self.c_net = net
+        self.arena = None
 
-def forward(net: nn.Module, plan: ResnetPlan, x: torch.Tensor) -> List[torch.Tensor]:
-    """[4 side outputs, fused], each [N,1,H,W] fp32 logits (src/networks/osvos_resnet.py:42-68)."""
+
+def _checked_input(net: nn.Module, x: torch.Tensor) -> torch.Tensor:
     if net.training:
         raise RuntimeError("OSVOS_RESNET runs eval-mode inference on the HIP path (BatchNorm folded from its running "
                            "statistics); training-mode forward/backward is not built - call net.eval()")
     if not x.is_cuda:
         raise RuntimeError("OSVOS_RESNET.forward: the input must live on the GPU (the HIP path has no CPU fallback)")
-    x = x.detach().contiguous().float()
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError(f"OSVOS_RESNET.forward: expected [N,3,H,W], got {tuple(x.shape)}")
+    return x.detach().contiguous().float()
+
+
+def forward_ops(net: nn.Module, plan: ResnetPlan, x: torch.Tensor) -> List[torch.Tensor]:
+    """The layer loop in Python, one C-ABI call per kernel (per-kernel timing with ops.OpProfiler, and the reference
+    point the native loop is tested against)."""
+    x = _checked_input(net, x)
     with torch.no_grad():
         plan.refresh(net)
         n, _c, h, w = x.shape
@@ -124,10 +159,31 @@ def forward(net: nn.Module, plan: ResnetPlan, x: torch.Tensor) -> List[torch.Ten
         for blocks, side in zip(plan.stages, plan.side):
             for blk in blocks:
                 y = blk(y)
-            if y.shape[3] != (side.ci + 7) // 8 * 8 or blocks[-1].convs[-1].co != side.ci:
+            if blocks[-1].convs[-1].co != side.ci:
                 raise RuntimeError(f"side_prep expects {side.ci} input channels, the stage produces "
                                    f"{blocks[-1].convs[-1].co}")
             sides.append(side(y, relu=False, out_f32=True))
         fused, outs = ops.deconv_head_fwd(sides, plan.strides, plan.filt, plan.filt1, plan.dsn_w, plan.dsn_b, plan.fuse_b,
                                           h, w, with_side_out=True)
     return outs + [fused]
+
+
+def forward(net: nn.Module, plan: ResnetPlan, x: torch.Tensor) -> List[torch.Tensor]:
+    """[4 side outputs, fused], each [N,1,H,W] fp32 logits (src/networks/osvos_resnet.py:42-68): one native call
+    issues every kernel of the pass."""
+    x = _checked_input(net, x)
+    plan.refresh(net)
+    n, _c, h, w = x.shape
+    L = lib()
+    need = L.fosvos_resnet_arena_bytes(ctypes.byref(plan.c_net), n, h, w)
+    if need == 0:
+        msg = L.fosvos_last_error().decode(errors="replace")
+        raise RuntimeError(f"OSVOS_RESNET.forward: {msg}")
+    if plan.arena is None or plan.arena.numel() < need or plan.arena.device != x.device:
+        plan.arena = torch.empty(need, dtype=torch.uint8, device=x.device)
+    outs = [torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device) for _ in range(5)]
+    dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    check(L.fosvos_resnet_forward(ctypes.byref(plan.c_net), x.data_ptr(), n, h, w, plan.arena.data_ptr(),
+                                  plan.arena.numel(), outs[4].data_ptr(), ptr_array4([o.data_ptr() for o in outs[:4]]), dev,
+                                  torch.cuda.current_stream(dev).cuda_stream), "resnet_forward")
+    return outs

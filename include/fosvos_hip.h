@@ -255,6 +255,39 @@ int fosvos_deconv_head_fwd(const float *const side[4], const int hs[4], const in
                            float *const side_out[4] /* all NULL or all set */, int N, int H, int W, int device,
                            void *stream);
 
+/* Whole-network forward of the ResNet family: ONE call issues every kernel of OSVOS_RESNET.forward (first conv, pool,
+ * every block with its residual branch, the four side_prep convs, the head) over a caller-provided arena.  The
+ * structs live in HOST memory for the duration of the call and hold device pointers to images made by the pack
+ * calls above; `blocks` is a host array listing the blocks stage after stage.
+ * replaces: OSVOS_RESNET.forward (src/networks/osvos_resnet.py:42-68) as driven from Python. */
+typedef struct fosvos_conv2d_desc {
+    const uint32_t *w_packed;
+    const float *bias;
+    int Ci, Co, k, stride;
+} fosvos_conv2d_desc;
+typedef struct fosvos_resnet_block {
+    fosvos_conv2d_desc conv[3]; /* conv+bn(+relu) chain; the last one adds the residual before its ReLU */
+    int n_convs;                /* 2 = BasicBlock, 3 = Bottleneck */
+    int has_down;
+    fosvos_conv2d_desc down;    /* 1x1 downsample conv + bn of the residual branch */
+} fosvos_resnet_block;
+typedef struct fosvos_resnet_net {
+    const float *first_w;       /* fosvos_pack_conv7x7_bn image */
+    const float *first_b;
+    int first_co;
+    int blocks_per_stage[4];
+    const fosvos_resnet_block *blocks;
+    fosvos_conv2d_desc side[4]; /* side_prep: 3x3 stride 1, Co = 16 */
+    const float *filt[4];       /* as fosvos_deconv_head_fwd */
+    const float *filt1[4];
+    int stride[4];
+    const float *dsn_w, *dsn_b, *fuse_b;
+} fosvos_resnet_net;
+size_t fosvos_resnet_arena_bytes(const fosvos_resnet_net *net, int N, int H, int W);
+/* fused: [N,1,H,W] fp32; side_out: four [N,1,H,W] fp32 buffers or NULL. */
+int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *frame, int N, int H, int W, void *arena,
+                          size_t arena_bytes, float *fused, float *const side_out[4], int device, void *stream);
+
 /* ---- whole-network entry points ------------------------------------------------------------------
  * The reference drives ~60 torch.nn calls per forward from Python (src/networks/osvos_vgg.py:61-83) and
  * autograd replays them backward.  Here the layer loop itself is native: ONE call issues every kernel of

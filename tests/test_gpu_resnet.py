@@ -171,6 +171,23 @@ def test_network_matches_oracle(version, e, hw):
     _check_net(net, sd, x)
 
 
+def test_native_loop_equals_the_op_by_op_loop():
+    from fosvos_hip import resnet_engine
+    from networks.osvos_resnet import OSVOS_RESNET
+    from oracle import osvos_resnet_ref as R
+    for version, e, hw in ((18, 1, (65, 99)), (34, 3, (128, 160))):
+        net = OSVOS_RESNET(pretrained=False, version=version, scale_down_exponent=e)
+        net.load_state_dict(R.make_state_dict(version, e, seed=3))
+        net = net.to(DEV).eval()
+        x = (50.0 * torch.randn(2, 3, *hw, generator=torch.Generator().manual_seed(5))).to(DEV)
+        a = net(x)
+        b = resnet_engine.forward_ops(net, net._plan, x)
+        a2 = net(x)                                          # the arena is reused
+        torch.cuda.synchronize()
+        for u, v, u2 in zip(a, b, a2):
+            assert torch.equal(u, v) and torch.equal(u, u2)
+
+
 def test_weight_update_repacks_and_batch_of_one_equals_batch_rows():
     from networks.osvos_resnet import OSVOS_RESNET
     from oracle import osvos_resnet_ref as R
@@ -220,7 +237,7 @@ def test_bottleneck_trunk_runs_once_side_prep_fits():
     from oracle import osvos_resnet_ref as R
     net = OSVOS_RESNET(pretrained=False, version=50, scale_down_exponent=3)
     x = 50.0 * torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(6))
-    with pytest.raises(RuntimeError, match="side_prep expects"):
+    with pytest.raises(RuntimeError, match="side_prep.*expects"):
         net.to(DEV).eval()(x.to(DEV))
     wide = [4 * c for c in (8, 16, 32, 64)]
     sd = R.make_state_dict(50, 3, seed=8, side_channels=wide)

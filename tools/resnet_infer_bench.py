@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "fosvos_amd"))
 
-from fosvos_hip import ops  # noqa: E402
+from fosvos_hip import ops, resnet_engine  # noqa: E402
 from networks.osvos_resnet import OSVOS_RESNET  # noqa: E402
 from oracle import osvos_resnet_ref as R  # noqa: E402  (checker + CPU baseline leg only)
 
@@ -51,7 +51,7 @@ for version, e in [tuple(int(v) for v in t.split(":")) for t in args.nets.split(
     prof = ops.OpProfiler(detail=args.detail)
     ops.set_profiler(prof)
     for _ in range(3):
-        net(x)
+        resnet_engine.forward_ops(net, net._plan, x)  # same kernels, one C-ABI call each, so that they can be timed apart
     agg = prof.summary()
     ops.set_profiler(None)
     by = {k: {"calls_per_frame": v["calls"] / 3, "ms_per_frame": v["ms"] / 3,
