@@ -23,6 +23,9 @@ using namespace fosvos;
 
 namespace {
 
+// internal epilogue flag (never crosses the ABI): ReLU after the addend has been added - the residual form
+constexpr unsigned kReluAfterAdd = 0x100u;
+
 struct ConvArgs {
     const uint16_t *x;         // [N,H,W,Cin] bf16, Cin % 32 == 0
     const uint16_t *w;         // packed [Cin/32][9][4][Co_pad][8]
@@ -405,6 +408,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] += av[e];
             }
+            if (a.flags & kReluAfterAdd) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+            }
             if (ok[it]) *reinterpret_cast<uint4 *>(yo + off[it]) = pack8(f);
         }
     } else {
@@ -507,6 +514,10 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int64
                 unpack8(*reinterpret_cast<const uint4 *>(a.addend + off), ad);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] += ad[e];
+            }
+            if (a.flags & kReluAfterAdd) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
             }
         }
         *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(a.y) + off) = pack8(f);
@@ -649,6 +660,22 @@ extern "C" int fosvos_conv3x3_fwd(const uint16_t *x, const uint16_t *w_packed, c
     ConvArgs a{};
     a.x = x; a.w = w_packed; a.bias = bias; a.relu_src = nullptr; a.addend = nullptr; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Cin = roundup(Ci, 32); a.Cout = Co; a.Co_pad = roundup(Co, 16); a.flags = flags;
+    return dispatch(a, Ci, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int fosvos_conv3x3_fwd_add(const uint16_t *x, const uint16_t *w_packed, const float *bias,
+                                      const uint16_t *addend, uint16_t *y, int N, int H, int W, int Ci, int Co,
+                                      unsigned flags, void *workspace, size_t workspace_bytes, int device,
+                                      void *stream) {
+    if (!addend) return fosvos_conv3x3_fwd(x, w_packed, bias, y, N, H, W, Ci, Co, flags, workspace, workspace_bytes, device, stream);
+    if (int rc = check_common(x, w_packed, y, N, H, W, Ci, Co, "conv3x3_fwd_add")) return rc;
+    FOSVOS_REQUIRE((flags & ~FOSVOS_CONV_RELU) == 0, FOSVOS_E_ARG, "conv3x3_fwd_add: unknown flags 0x%x", flags);
+    FOSVOS_REQUIRE(Co % 64 == 0, FOSVOS_E_SHAPE, "conv3x3_fwd_add: Co=%d must be a multiple of 64", Co);
+    FOSVOS_ENTER(device);
+    ConvArgs a{};
+    a.x = x; a.w = w_packed; a.bias = bias; a.relu_src = nullptr; a.addend = addend; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = roundup(Ci, 32); a.Cout = Co; a.Co_pad = roundup(Co, 16);
+    a.flags = (flags & FOSVOS_CONV_RELU) ? kReluAfterAdd : 0u;
     return dispatch(a, Ci, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

@@ -60,6 +60,21 @@ __global__ void k_pack_conv2d_bn(const float *__restrict__ w, int Co, int Ci, in
     wp[i] = v;
 }
 
+// The fold alone, fp32 OIHW -> fp32 OIHW (layers that continue through the MFMA path's own packing).
+__global__ void k_fold_conv_bn(const float *__restrict__ w, int Co, int per_co, const float *__restrict__ conv_bias,
+                               const float *__restrict__ bn_w, const float *__restrict__ bn_b,
+                               const float *__restrict__ bn_m, const float *__restrict__ bn_v, float eps,
+                               float *__restrict__ wo, float *__restrict__ bias_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Co) {
+        const float s = bn_w ? bn_w[i] / sqrtf(bn_v[i] + eps) : 1.f;
+        bias_out[i] = (bn_w ? bn_b[i] - bn_m[i] * s : 0.f) + (conv_bias ? conv_bias[i] * s : 0.f);
+    }
+    if (i >= (int64_t)Co * per_co) return;
+    const int co = (int)(i / per_co);
+    wo[i] = w[i] * (bn_w ? bn_w[co] / sqrtf(bn_v[co] + eps) : 1.f);
+}
+
 // First layer: [Co][3][7][7] fp32 -> [tap * 3 + ci][Cop] fp32 (the frame stays fp32, so do the weights).
 __global__ void k_pack_conv7x7_bn(const float *__restrict__ w, int Co, const float *__restrict__ bn_w,
                                   const float *__restrict__ bn_b, const float *__restrict__ bn_m,
@@ -193,46 +208,48 @@ __global__ __launch_bounds__(SLICED ? 512 : 256) void k_conv2d(const uint4 *__re
 }
 
 // ------------------------------------------------------------------------------------------ 7x7 stride-2 first layer
-// frame fp32 NCHW [N,3,H,W] -> bf16 NHWC [N,Ho,Wo,Cop]; fp32 multiply-add with the weights as scalar operands.
+// frame fp32 NCHW [N,3,H,W] -> bf16 NHWC [N,Ho,Wo,Cop]; fp32 multiply-add with the weights as scalar operands.  A
+// workgroup owns 8 x 32 output pixels and stages their 21 x 69 x 3 input patch in LDS (coalesced row reads, zeros
+// outside the frame); the 147 taps of a thread then come from LDS (odd row pitch: the stride-2 reads of a wave's two
+// half-rows fall on distinct banks) instead of 147 half-used global loads.
+constexpr int F7_TH = 8, F7_TW = 32, F7_PH = F7_TH * 2 + 5, F7_PW = F7_TW * 2 + 5;
+
 template <int COB>
 __global__ __launch_bounds__(256) void k_conv7x7s2_first(const float *__restrict__ frame, const float *__restrict__ wp,
-                                                         const float *__restrict__ bias, uint4 *__restrict__ y, int N,
-                                                         int H, int W, int Ho, int Wo, int Cop, int relu) {
-    const int64_t npix = (int64_t)N * Ho * Wo;
-    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = pix < npix;
-    const int64_t pc = live ? pix : npix - 1;
-    const int ox = (int)(pc % Wo), oy = (int)((pc / Wo) % Ho), n = (int)(pc / ((int64_t)Wo * Ho));
-    const int cb = blockIdx.y;
+                                                         const float *__restrict__ bias, uint4 *__restrict__ y, int H,
+                                                         int W, int Ho, int Wo, int tiles_x, int Cop, int relu) {
+    __shared__ float sIn[3 * F7_PH * F7_PW];
+    const int tile = blockIdx.x, cb = blockIdx.y, n = blockIdx.z;
+    const int oy0 = (tile / tiles_x) * F7_TH, ox0 = (tile % tiles_x) * F7_TW;
     const int64_t plane = (int64_t)H * W;
     const float *f0 = frame + (int64_t)n * 3 * plane;
+    for (int idx = threadIdx.x; idx < 3 * F7_PH * F7_PW; idx += 256) {
+        const int ci = idx / (F7_PH * F7_PW), r = (idx / F7_PW) % F7_PH, c = idx % F7_PW;
+        const int iy = oy0 * 2 - 3 + r, ix = ox0 * 2 - 3 + c;
+        sIn[idx] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? f0[ci * plane + (int64_t)iy * W + ix] : 0.f;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % F7_TW, ly = threadIdx.x / F7_TW;
     float acc[COB];
 #pragma unroll
     for (int j = 0; j < COB; ++j) acc[j] = 0.f;
 #pragma unroll 1
     for (int ky = 0; ky < 7; ++ky) {
-        const int iy = oy * 2 + ky - 3;
-        const bool row_ok = iy >= 0 && iy < H;
-        const float *frow = f0 + (int64_t)min(max(iy, 0), H - 1) * W;
+        const float *row = sIn + (ly * 2 + ky) * F7_PW + lx * 2;
         float v[21];
 #pragma unroll
-        for (int kx = 0; kx < 7; ++kx) {
-            const int ix = ox * 2 + kx - 3;
-            const bool ok = row_ok && ix >= 0 && ix < W;
-            const int ixc = min(max(ix, 0), W - 1);
+        for (int kx = 0; kx < 7; ++kx)
 #pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                const float t = frow[ci * plane + ixc];
-                v[kx * 3 + ci] = ok ? t : 0.f;
-            }
-        }
+            for (int ci = 0; ci < 3; ++ci) v[kx * 3 + ci] = row[ci * (F7_PH * F7_PW) + kx];
         const float *wr = wp + (int64_t)(ky * 21) * Cop + cb * COB;  // uniform: scalar loads
 #pragma unroll
         for (int q = 0; q < 21; ++q)
 #pragma unroll
             for (int j = 0; j < COB; ++j) acc[j] = fmaf(v[q], wr[q * Cop + j], acc[j]);
     }
-    if (!live) return;
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    if (oy >= Ho || ox >= Wo) return;
+    const int64_t pix = ((int64_t)n * Ho + oy) * Wo + ox;
     const int cop8 = Cop >> 3;
 #pragma unroll
     for (int g = 0; g < COB / 8; ++g) {
@@ -293,15 +310,20 @@ struct DeconvHeadArgs {
     int N, H, W, with_side_out;
 };
 
-// A thread owns DH_PX pixels of one row, 64 columns apart: every stride divides 64, so they share the filter phase
-// (ky, kx) at every scale and the 4 taps x 16 channels of filter are fetched once per scale for all of them - the
-// filter rows (64 B per lane, all lanes different) are what the L1 path spends its time on, the side maps are read by
-// groups of f lanes at the same address.
-constexpr int DH_PX = 8;
+// A workgroup owns 4 rows x 512 columns; a thread owns DH_PX pixels of one row, 64 columns apart: every stride
+// divides 64, so they share the filter phase (ky, kx) at every scale and the 4 taps x 16 channels of filter live in
+// registers for all of them.  Per scale the side-map window under the tile (3 rows x (512 / f + 2) pixels, zeros
+// outside the map) is staged in LDS together with its score_dsn value d = dsn_b + dsn_w . side, computed once per
+// source pixel instead of once per output pixel and tap; the taps then read LDS (groups of f lanes share an address).
+constexpr int DH_PX = 8, DH_ROWS = 4, DH_COLS = 64 * DH_PX;
+constexpr int DH_NR = 3, DH_NC = DH_COLS / 4 + 2;  // window bound at the smallest stride (4)
 
 __global__ __launch_bounds__(256) void k_deconv_head(const DeconvHeadArgs g) {
-    const int X0 = blockIdx.x * (64 * DH_PX) + threadIdx.x, Y = blockIdx.y * 4 + threadIdx.y, n = blockIdx.z;
-    if (Y >= g.H || X0 >= g.W) return;
+    __shared__ float4 sS[DH_NR * DH_NC * 4];
+    __shared__ float sD[DH_NR * DH_NC];
+    const int Xb = blockIdx.x * DH_COLS, Yb = blockIdx.y * DH_ROWS, n = blockIdx.z;
+    const int X0 = Xb + threadIdx.x, Y = Yb + threadIdx.y;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
     float fused[DH_PX];
     const float fb = g.fuse_b[0];
 #pragma unroll
@@ -309,58 +331,79 @@ __global__ __launch_bounds__(256) void k_deconv_head(const DeconvHeadArgs g) {
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
         const int f = g.f[s], k = 2 * f, hs = g.hs[s], ws = g.ws[s], jstep = 64 / f;
+        const int r_lo = (Yb + g.top[s]) / f - 1, c_lo = (Xb + g.left[s]) / f - 1, nc = DH_COLS / f + 2;
         const int yy = Y + g.top[s], xx = X0 + g.left[s];
         const int i0 = yy / f, ky0 = yy - i0 * f, j0 = xx / f, kx0 = xx - j0 * f;
-        float dw[16];
-        float db = 0.f;
-        if (g.with_side_out) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) dw[c] = g.dsn_w[s * 16 + c];
-            db = g.dsn_b[s];
+        // the filter of tap (a, b) sits at [ky0 + a f][kx0 + b f]; tap 0's is requested before the window is staged and
+        // tap t + 1's while tap t is multiplied, so no tap waits out a global round trip
+        const float4 *fbase = reinterpret_cast<const float4 *>(g.filt[s]);
+        const float *f1base = g.filt1[s];
+        int fidx = ky0 * k + kx0;
+        float4 n0 = fbase[fidx * 4 + 0], n1 = fbase[fidx * 4 + 1], n2 = fbase[fidx * 4 + 2], n3 = fbase[fidx * 4 + 3];
+        float nw = g.with_side_out ? f1base[fidx] : 0.f;
+        __syncthreads();  // the previous scale's window has been consumed
+        for (int idx = tid; idx < DH_NR * nc; idx += 256) {
+            const int r = idx / nc, c = idx - r * nc, i = r_lo + r, j = c_lo + c;
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0, v3 = v0;
+            float d = 0.f;
+            if (i >= 0 && i < hs && j >= 0 && j < ws) {
+                const float4 *sp = reinterpret_cast<const float4 *>(g.side[s]) + (((int64_t)n * hs + i) * ws + j) * 4;
+                v0 = sp[0], v1 = sp[1], v2 = sp[2], v3 = sp[3];
+                if (g.with_side_out) {
+                    const float4 *dw = reinterpret_cast<const float4 *>(g.dsn_w) + s * 4;
+                    const float4 w0 = dw[0], w1 = dw[1], w2 = dw[2], w3 = dw[3];
+                    d = g.dsn_b[s];
+                    d = fmaf(v0.x, w0.x, d); d = fmaf(v0.y, w0.y, d); d = fmaf(v0.z, w0.z, d); d = fmaf(v0.w, w0.w, d);
+                    d = fmaf(v1.x, w1.x, d); d = fmaf(v1.y, w1.y, d); d = fmaf(v1.z, w1.z, d); d = fmaf(v1.w, w1.w, d);
+                    d = fmaf(v2.x, w2.x, d); d = fmaf(v2.y, w2.y, d); d = fmaf(v2.z, w2.z, d); d = fmaf(v2.w, w2.w, d);
+                    d = fmaf(v3.x, w3.x, d); d = fmaf(v3.y, w3.y, d); d = fmaf(v3.z, w3.z, d); d = fmaf(v3.w, w3.w, d);
+                }
+            }
+            sS[idx * 4 + 0] = v0;
+            sS[idx * 4 + 1] = v1;
+            sS[idx * 4 + 2] = v2;
+            sS[idx * 4 + 3] = v3;
+            sD[idx] = d;
         }
+        __syncthreads();
         float so[DH_PX];
 #pragma unroll
         for (int p = 0; p < DH_PX; ++p) so[p] = 0.f;
+        // (the tap loop stays rolled: unrolled, hipcc keeps all four taps' filters and window reads live - 512 VGPRs and
+        // scratch)
+#pragma unroll 1
+        for (int tap = 0; tap < 4; ++tap) {
+            const int a = tap >> 1, b = tap & 1;
+            const int r = i0 - a - r_lo;  // 0..2
+            const float4 f0 = n0, f1 = n1, f2 = n2, f3 = n3;
+            const float w1 = nw;
+            if (tap < 3) {
+                const int ta = (tap + 1) >> 1, tb = (tap + 1) & 1;
+                fidx = (ky0 + ta * f) * k + kx0 + tb * f;
+                n0 = fbase[fidx * 4 + 0], n1 = fbase[fidx * 4 + 1], n2 = fbase[fidx * 4 + 2], n3 = fbase[fidx * 4 + 3];
+                nw = g.with_side_out ? f1base[fidx] : 0.f;
+            }
+            const int base = r * nc + (j0 - b - c_lo);
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int i = i0 - a, ky = ky0 + a * f;
-            if (i < 0 || i >= hs) continue;
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int kx = kx0 + b * f;
-                const float4 *fp = reinterpret_cast<const float4 *>(g.filt[s]) + ((int64_t)ky * k + kx) * 4;
-                const float4 f0 = fp[0], f1 = fp[1], f2 = fp[2], f3 = fp[3];
-                const float w1 = g.with_side_out ? g.filt1[s][ky * k + kx] : 0.f;
-                const float4 *srow = reinterpret_cast<const float4 *>(g.side[s]) + ((int64_t)n * hs + i) * ws * 4;
-#pragma unroll
-                for (int p = 0; p < DH_PX; ++p) {
-                    const int j = j0 + p * jstep - b;
-                    if (X0 + 64 * p >= g.W || j < 0 || j >= ws) continue;
-                    const float4 *sp = srow + (int64_t)j * 4;
-                    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
-                    float t = fused[p];
-                    t = fmaf(s0.x, f0.x, t); t = fmaf(s0.y, f0.y, t); t = fmaf(s0.z, f0.z, t); t = fmaf(s0.w, f0.w, t);
-                    t = fmaf(s1.x, f1.x, t); t = fmaf(s1.y, f1.y, t); t = fmaf(s1.z, f1.z, t); t = fmaf(s1.w, f1.w, t);
-                    t = fmaf(s2.x, f2.x, t); t = fmaf(s2.y, f2.y, t); t = fmaf(s2.z, f2.z, t); t = fmaf(s2.w, f2.w, t);
-                    t = fmaf(s3.x, f3.x, t); t = fmaf(s3.y, f3.y, t); t = fmaf(s3.z, f3.z, t); t = fmaf(s3.w, f3.w, t);
-                    fused[p] = t;
-                    if (g.with_side_out) {
-                        float d = db;
-                        d = fmaf(s0.x, dw[0], d); d = fmaf(s0.y, dw[1], d); d = fmaf(s0.z, dw[2], d); d = fmaf(s0.w, dw[3], d);
-                        d = fmaf(s1.x, dw[4], d); d = fmaf(s1.y, dw[5], d); d = fmaf(s1.z, dw[6], d); d = fmaf(s1.w, dw[7], d);
-                        d = fmaf(s2.x, dw[8], d); d = fmaf(s2.y, dw[9], d); d = fmaf(s2.z, dw[10], d); d = fmaf(s2.w, dw[11], d);
-                        d = fmaf(s3.x, dw[12], d); d = fmaf(s3.y, dw[13], d); d = fmaf(s3.z, dw[14], d); d = fmaf(s3.w, dw[15], d);
-                        so[p] = fmaf(w1, d, so[p]);
-                    }
-                }
+            for (int p = 0; p < DH_PX; ++p) {
+                const int idx = base + p * jstep;
+                const float4 s0 = sS[idx * 4 + 0], s1 = sS[idx * 4 + 1], s2 = sS[idx * 4 + 2], s3 = sS[idx * 4 + 3];
+                float t = fused[p];
+                t = fmaf(s0.x, f0.x, t); t = fmaf(s0.y, f0.y, t); t = fmaf(s0.z, f0.z, t); t = fmaf(s0.w, f0.w, t);
+                t = fmaf(s1.x, f1.x, t); t = fmaf(s1.y, f1.y, t); t = fmaf(s1.z, f1.z, t); t = fmaf(s1.w, f1.w, t);
+                t = fmaf(s2.x, f2.x, t); t = fmaf(s2.y, f2.y, t); t = fmaf(s2.z, f2.z, t); t = fmaf(s2.w, f2.w, t);
+                t = fmaf(s3.x, f3.x, t); t = fmaf(s3.y, f3.y, t); t = fmaf(s3.z, f3.z, t); t = fmaf(s3.w, f3.w, t);
+                fused[p] = t;
+                so[p] = fmaf(w1, sD[idx], so[p]);
             }
         }
-        if (g.with_side_out) {
+        if (g.with_side_out && Y < g.H) {
 #pragma unroll
             for (int p = 0; p < DH_PX; ++p)
                 if (X0 + 64 * p < g.W) g.side_out[s][((int64_t)n * g.H + Y) * g.W + X0 + 64 * p] = so[p];
         }
     }
+    if (Y >= g.H) return;
 #pragma unroll
     for (int p = 0; p < DH_PX; ++p)
         if (X0 + 64 * p < g.W) g.fused[((int64_t)n * g.H + Y) * g.W + X0 + 64 * p] = fused[p];
@@ -437,6 +480,21 @@ extern "C" int fosvos_pack_conv2d_bn(const float *w_oihw, int Co, int Ci, int k,
     return 0;
 }
 
+extern "C" int fosvos_fold_conv_bn(const float *w_oihw, int Co, int Ci, int k, const float *conv_bias,
+                                   const float *bn_weight, const float *bn_bias, const float *bn_mean,
+                                   const float *bn_var, float eps, float *w_folded, float *bias_out, int device,
+                                   void *stream) {
+    FOSVOS_REQUIRE(w_oihw && w_folded && bias_out, FOSVOS_E_ARG, "fold_conv_bn: null pointer");
+    FOSVOS_REQUIRE(Co > 0 && Ci > 0 && k > 0, FOSVOS_E_ARG, "fold_conv_bn: Co=%d Ci=%d k=%d", Co, Ci, k);
+    FOSVOS_REQUIRE(!bn_weight || (bn_bias && bn_mean && bn_var), FOSVOS_E_ARG, "fold_conv_bn: partial BatchNorm");
+    FOSVOS_ENTER(device);
+    const int per_co = Ci * k * k;
+    hipLaunchKernelGGL(k_fold_conv_bn, dim3((unsigned)cdiv((int64_t)Co * per_co, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, Co, per_co, conv_bias, bn_weight, bn_bias, bn_mean, bn_var, eps, w_folded, bias_out);
+    FOSVOS_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int fosvos_conv2d_fwd(const uint16_t *x, const uint32_t *w_packed, const float *bias, const uint16_t *addend,
                                  void *y, int N, int H, int W, int Ci, int Co, int k, int stride, unsigned flags,
                                  int device, void *stream) {
@@ -505,14 +563,15 @@ extern "C" int fosvos_conv7x7s2_first_fwd(const float *frame, const float *w_pac
     FOSVOS_REQUIRE((flags & ~(unsigned)FOSVOS_CONV_RELU) == 0, FOSVOS_E_ARG, "conv7x7s2_first_fwd: flags 0x%x", flags);
     FOSVOS_ENTER(device);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, Cop = roundup(Co, 8);
-    const int64_t npix = (int64_t)N * Ho * Wo;
-    ConvLaunch L = plan_conv2d(npix, Cop, 1);
-    const dim3 grid((unsigned)cdiv(npix, L.threads), (unsigned)cdiv(Cop, L.cob));
+    FOSVOS_REQUIRE(N < 65536, FOSVOS_E_ARG, "conv7x7s2_first_fwd: N=%d", N);
+    const ConvLaunch L = plan_conv2d((int64_t)N * Ho * Wo, Cop, 1);
+    const int tiles_x = (int)cdiv(Wo, F7_TW), tiles_y = (int)cdiv(Ho, F7_TH);
+    const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)cdiv(Cop, L.cob), (unsigned)N);
     const int relu = (flags & FOSVOS_CONV_RELU) ? 1 : 0;
     uint4 *yv = reinterpret_cast<uint4 *>(y);
-#define FOSVOS_GO(COB)                                                                                                 \
-    hipLaunchKernelGGL(k_conv7x7s2_first<COB>, grid, dim3(L.threads), 0, (hipStream_t)stream, frame, w_packed, bias, yv, N, \
-                       H, W, Ho, Wo, Cop, relu)
+#define FOSVOS_GO(COB)                                                                                                \
+    hipLaunchKernelGGL(k_conv7x7s2_first<COB>, grid, dim3(256), 0, (hipStream_t)stream, frame, w_packed, bias, yv, H, W, Ho, \
+                       Wo, tiles_x, Cop, relu)
     switch (L.cob) {
         case 64: FOSVOS_GO(64); break;
         case 32: FOSVOS_GO(32); break;
@@ -550,8 +609,8 @@ extern "C" int fosvos_deconv_head_fwd(const float *const side[4], const int hs[4
         FOSVOS_REQUIRE(side[s] && filt[s], FOSVOS_E_ARG, "deconv_head_fwd: null side/filter pointer at scale %d", s);
         FOSVOS_REQUIRE(hs[s] > 0 && ws[s] > 0 && stride[s] > 0, FOSVOS_E_ARG, "deconv_head_fwd: scale %d is %dx%d stride %d",
                        s, hs[s], ws[s], stride[s]);
-        FOSVOS_REQUIRE(64 % stride[s] == 0, FOSVOS_E_SHAPE, "deconv_head_fwd: stride %d of scale %d does not divide 64",
-                       stride[s], s);
+        FOSVOS_REQUIRE(stride[s] >= 4 && 64 % stride[s] == 0, FOSVOS_E_SHAPE,
+                       "deconv_head_fwd: stride %d of scale %d (4, 8, 16, 32 or 64)", stride[s], s);
         const int dh = (hs[s] + 1) * stride[s], dw = (ws[s] + 1) * stride[s];  // (h-1) f + 2f
         FOSVOS_REQUIRE(dh >= H && dw >= W, FOSVOS_E_ARG,
                        "deconv_head_fwd: scale %d upsamples to %dx%d, smaller than the %dx%d frame", s, dh, dw, H, W);
@@ -577,7 +636,7 @@ extern "C" int fosvos_deconv_head_fwd(const float *const side[4], const int hs[4
     g.W = W;
     g.with_side_out = so ? 1 : 0;
     FOSVOS_ENTER(device);
-    hipLaunchKernelGGL(k_deconv_head, dim3((unsigned)cdiv(W, 64 * DH_PX), (unsigned)cdiv(H, 4), (unsigned)N), dim3(64, 4), 0,
+    hipLaunchKernelGGL(k_deconv_head, dim3((unsigned)cdiv(W, DH_COLS), (unsigned)cdiv(H, DH_ROWS), (unsigned)N), dim3(64, DH_ROWS), 0,
                        (hipStream_t)stream, g);
     FOSVOS_LAUNCH_CHECK();
     return 0;
@@ -595,7 +654,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // Arena: [first conv output][4 rotating activation slots of the largest block tensor][4 fp32 side maps]
 struct ResnetLayout {
-    size_t first_bytes, slot_bytes, side_off[4], side_bytes[4], total;
+    size_t first_bytes, slot_bytes, side_off[4], side_bytes[4], ws_off, ws_bytes, total;
     int hs[4], ws[4];
 };
 
@@ -607,7 +666,7 @@ int resnet_layout(const fosvos_resnet_net *net, int N, int H, int W, ResnetLayou
     L->first_bytes = align256(a.bytes(N));
     a.h = (a.h - 1) / 2 + 1;
     a.w = (a.w - 1) / 2 + 1;
-    size_t slot = a.bytes(N);
+    size_t slot = a.bytes(N), ws = 0;
     int b = 0;
     for (int s = 0; s < 4; ++s) {
         FOSVOS_REQUIRE(net->blocks_per_stage[s] > 0, FOSVOS_E_ARG, "resnet: stage %d has no blocks", s);
@@ -619,12 +678,20 @@ int resnet_layout(const fosvos_resnet_net *net, int N, int H, int W, ResnetLayou
                 const fosvos_conv2d_desc &c = blk.conv[q];
                 FOSVOS_REQUIRE(c.w_packed && c.bias && c.Ci == y.c, FOSVOS_E_SHAPE,
                                "resnet: block %d conv %d takes %d channels, its input has %d", b, q + 1, c.Ci, y.c);
+                if (c.kind == 1) {
+                    FOSVOS_REQUIRE(c.k == 3 && c.stride == 1 && c.Ci % 32 == 0 && c.Co % 64 == 0, FOSVOS_E_SHAPE,
+                                   "resnet: block %d conv %d (%d -> %d, k %d, stride %d) does not fit the MFMA path", b, q + 1,
+                                   c.Ci, c.Co, c.k, c.stride);
+                    ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, y.h, y.w, c.Ci, c.Co));
+                } else {
+                    FOSVOS_REQUIRE(c.kind == 0, FOSVOS_E_ARG, "resnet: block %d conv %d has kind %d", b, q + 1, c.kind);
+                }
                 y = ActShape{conv_out(y.h, c.k, c.stride), conv_out(y.w, c.k, c.stride), c.Co};
                 slot = std::max(slot, y.bytes(N));
             }
             ActShape r = a;
             if (blk.has_down) {
-                FOSVOS_REQUIRE(blk.down.w_packed && blk.down.bias && blk.down.Ci == a.c, FOSVOS_E_SHAPE,
+                FOSVOS_REQUIRE(blk.down.w_packed && blk.down.bias && blk.down.Ci == a.c && blk.down.kind == 0, FOSVOS_E_SHAPE,
                                "resnet: block %d downsample takes %d channels, its input has %d", b, blk.down.Ci, a.c);
                 r = ActShape{conv_out(a.h, blk.down.k, blk.down.stride), conv_out(a.w, blk.down.k, blk.down.stride), blk.down.Co};
                 slot = std::max(slot, r.bytes(N));
@@ -634,8 +701,13 @@ int resnet_layout(const fosvos_resnet_net *net, int N, int H, int W, ResnetLayou
             a = y;
         }
         const fosvos_conv2d_desc &sp = net->side[s];
-        FOSVOS_REQUIRE(sp.w_packed && sp.bias && sp.Co == 16 && sp.k == 3 && sp.stride == 1, FOSVOS_E_SHAPE,
-                       "resnet: side_prep %d must be a 3x3 stride-1 conv to 16 channels", s);
+        FOSVOS_REQUIRE(sp.w_packed && sp.bias && sp.Co == 16 && sp.k == 3 && sp.stride == 1 && (sp.kind == 0 || sp.kind == 1),
+                       FOSVOS_E_SHAPE, "resnet: side_prep %d must be a 3x3 stride-1 conv to 16 channels", s);
+        if (sp.kind == 1) {
+            FOSVOS_REQUIRE(sp.Ci % 32 == 0, FOSVOS_E_SHAPE, "resnet: side_prep %d (%d channels in) does not fit the MFMA path", s,
+                           sp.Ci);
+            ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.h, a.w, sp.Ci, 16));
+        }
         FOSVOS_REQUIRE(sp.Ci == a.c, FOSVOS_E_SHAPE, "resnet: side_prep %d expects %d input channels, the stage produces %d", s,
                        sp.Ci, a.c);
         L->hs[s] = a.h;
@@ -648,7 +720,9 @@ int resnet_layout(const fosvos_resnet_net *net, int N, int H, int W, ResnetLayou
         L->side_off[s] = off;
         off += L->side_bytes[s];
     }
-    L->total = off + 256;
+    L->ws_off = off;
+    L->ws_bytes = align256(ws);
+    L->total = off + L->ws_bytes + 256;
     return 0;
 }
 
@@ -692,7 +766,7 @@ extern "C" int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *
             int res = cur;
             if (blk.has_down) {
                 res = other(cur, -1, -1);
-                if (int rc = fosvos_conv2d_fwd(slot[cur], blk.down.w_packed, blk.down.bias, nullptr, slot[res], N, h, w,
+                if (int rc = fosvos_conv2d_fwd(slot[cur], reinterpret_cast<const uint32_t *>(blk.down.w_packed), blk.down.bias, nullptr, slot[res], N, h, w,
                                                blk.down.Ci, blk.down.Co, blk.down.k, blk.down.stride, 0, device, stream))
                     return rc;
             }
@@ -701,9 +775,15 @@ extern "C" int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *
                 const fosvos_conv2d_desc &c = blk.conv[q];
                 const bool last = q == blk.n_convs - 1;
                 const int out = other(in, res, last ? -1 : cur);  // (the block input stays live until the residual is taken)
-                if (int rc = fosvos_conv2d_fwd(slot[in], c.w_packed, c.bias, last ? slot[res] : nullptr, slot[out], N, ih, iw,
-                                               c.Ci, c.Co, c.k, c.stride, FOSVOS_CONV_RELU, device, stream))
-                    return rc;
+                const uint16_t *add = last ? slot[res] : nullptr;
+                const int rc = c.kind == 1
+                                   ? fosvos_conv3x3_fwd_add(slot[in], reinterpret_cast<const uint16_t *>(c.w_packed), c.bias, add,
+                                                            slot[out], N, ih, iw, c.Ci, c.Co, FOSVOS_CONV_RELU, base + L.ws_off,
+                                                            L.ws_bytes, device, stream)
+                                   : fosvos_conv2d_fwd(slot[in], reinterpret_cast<const uint32_t *>(c.w_packed), c.bias, add,
+                                                       slot[out], N, ih, iw, c.Ci, c.Co, c.k, c.stride, FOSVOS_CONV_RELU, device,
+                                                       stream);
+                if (rc) return rc;
                 ih = conv_out(ih, c.k, c.stride);
                 iw = conv_out(iw, c.k, c.stride);
                 in = out;
@@ -714,9 +794,12 @@ extern "C" int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *
         }
         float *sm = reinterpret_cast<float *>(base + L.side_off[s]);
         const fosvos_conv2d_desc &sp = net->side[s];
-        if (int rc = fosvos_conv2d_fwd(slot[cur], sp.w_packed, sp.bias, nullptr, sm, N, h, w, sp.Ci, sp.Co, 3, 1,
-                                       FOSVOS_CONV_OUT_F32, device, stream))
-            return rc;
+        const int rc = sp.kind == 1 ? fosvos_conv3x3_fwd(slot[cur], reinterpret_cast<const uint16_t *>(sp.w_packed), sp.bias, sm, N, h,
+                                                         w, sp.Ci, 16, FOSVOS_CONV_OUT_F32, base + L.ws_off, L.ws_bytes, device,
+                                                         stream)
+                                    : fosvos_conv2d_fwd(slot[cur], reinterpret_cast<const uint32_t *>(sp.w_packed), sp.bias, nullptr,
+                                                        sm, N, h, w, sp.Ci, sp.Co, 3, 1, FOSVOS_CONV_OUT_F32, device, stream);
+        if (rc) return rc;
         side[s] = sm;
     }
     return fosvos_deconv_head_fwd(side, L.hs, L.ws, net->stride, net->filt, net->filt1, net->dsn_w, net->dsn_b, net->fuse_b,

@@ -55,7 +55,8 @@ class PackEntry(ctypes.Structure):
 
 class Conv2dDesc(ctypes.Structure):
     """fosvos_conv2d_desc."""
-    _fields_ = [("w_packed", c_void_p), ("bias", c_void_p), ("Ci", c_int), ("Co", c_int), ("k", c_int), ("stride", c_int)]
+    _fields_ = [("w_packed", c_void_p), ("bias", c_void_p), ("Ci", c_int), ("Co", c_int), ("k", c_int), ("stride", c_int),
+                ("kind", c_int)]
 
 
 class ResnetBlock(ctypes.Structure):
@@ -116,6 +117,10 @@ SIGNATURES = {
                                  c_int, c_void_p]),
     "fosvos_cbce_workspace_bytes": (c_size_t, [c_int64]),
     "fosvos_sgd_momentum_step": (c_int, [c_void_p, c_int, c_int64, c_float, c_int, c_int, c_void_p]),
+    "fosvos_conv3x3_fwd_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                       c_uint, c_void_p, c_size_t, c_int, c_void_p]),
+    "fosvos_fold_conv_bn": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_float, c_void_p, c_void_p, c_int, c_void_p]),
     "fosvos_conv2d_packed_dwords": (c_size_t, [c_int, c_int, c_int]),
     "fosvos_conv2d_bias_elems": (c_size_t, [c_int]),
     "fosvos_pack_conv2d_bn": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -462,6 +462,57 @@ def cbce_loss(logits: torch.Tensor, label: torch.Tensor, size_average: bool = Tr
 
 
 # ------------------------------------------------------------------------------------------ thin-channel ResNet path
+def fold_conv_bn(w: torch.Tensor, conv_bias: Optional[torch.Tensor] = None, bn: Optional[Sequence] = None):
+    """(w * s, bn_bias - mean * s [+ conv_bias * s]) with s = bn_weight / sqrt(var + eps): fp32 OIHW in and out."""
+    _need(w, _F32, "fold_conv_bn weight")
+    co, ci, k, k2 = w.shape
+    if k != k2:
+        raise ValueError("fold_conv_bn: square kernels only")
+    out = torch.empty_like(w)
+    bias = torch.empty((co,), dtype=_F32, device=w.device)
+    bnp = [None] * 4
+    eps = 0.0
+    if bn is not None:
+        for t in bn[:4]:
+            _need(t, _F32, "fold_conv_bn BatchNorm tensor")
+            if t.numel() != co:
+                raise ValueError("fold_conv_bn: BatchNorm size != out channels")
+        bnp = [t.data_ptr() for t in bn[:4]]
+        eps = float(bn[4])
+    if conv_bias is not None:
+        _need(conv_bias, _F32, "fold_conv_bn conv bias")
+    dev, st = _ctx(w)
+    check(lib().fosvos_fold_conv_bn(w.data_ptr(), co, ci, k, _p(conv_bias), bnp[0], bnp[1], bnp[2], bnp[3], eps,
+                                    out.data_ptr(), bias.data_ptr(), dev, st), "fold_conv_bn")
+    return out, bias
+
+
+def conv3x3_fwd_add(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, ci: int, co: int, relu: bool = True,
+                    addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """MFMA conv3x3 in its residual form: act(conv(x) + bias + addend), ReLU after the add; bf16 NHWC in and out."""
+    _need(x, _BF16, "conv3x3_fwd_add x"); _need(w_packed, _BF16, "conv3x3_fwd_add packed weight")
+    _need(bias, _F32, "conv3x3_fwd_add bias")
+    n, h, wd, cx = x.shape
+    L = lib()
+    if cx != ci or ci % 32 or co % 64:
+        raise ValueError(f"conv3x3_fwd_add: x has {cx} channels for Ci={ci}, Co={co} (Ci % 32 == 0, Co % 64 == 0)")
+    if w_packed.numel() != L.fosvos_packed_weight_elems(co, ci) or bias.numel() != co:
+        raise ValueError("conv3x3_fwd_add: packed weight / bias size does not match (Co, Ci)")
+    y = torch.empty((n, h, wd, co), dtype=_BF16, device=x.device)
+    if addend is not None:
+        _need(addend, _BF16, "conv3x3_fwd_add addend")
+        if addend.shape != y.shape:
+            raise ValueError(f"conv3x3_fwd_add: addend {tuple(addend.shape)} vs output {tuple(y.shape)}")
+    ws, wsn = _WS.get(L.fosvos_conv3x3_workspace_bytes(n, h, wd, ci, co), x.device)
+    dev, st = _ctx(x)
+    t0 = _pb()
+    check(L.fosvos_conv3x3_fwd_add(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), _p(addend), y.data_ptr(), n, h, wd, ci,
+                                   co, CONV_RELU if relu else 0, ws, wsn, dev, st), "conv3x3_fwd_add")
+    _pe(t0, f"mfma3x3s1 {ci}->{co} @{h}x{wd}" if _PROF is not None and _PROF.detail else "mfma3x3s1",
+        2.0 * n * h * wd * 9 * ci * co, 2 * (x.numel() + y.numel()) + (2 * addend.numel() if addend is not None else 0))
+    return y
+
+
 def conv_out_size(h: int, k: int, stride: int) -> int:
     return (h + 2 * (k // 2) - k) // stride + 1
 

@@ -14,15 +14,22 @@ import torch
 import torch.nn as nn
 
 import ctypes
+import os
 
 from . import Conv2dDesc, ResnetBlock, ResnetNet, check, lib, ops, ptr_array4
 
 
-class _Conv:
-    """One packed conv (+ folded BatchNorm): what ops.conv2d_fwd needs."""
-    __slots__ = ("packed", "bias", "ci", "co", "k", "stride")
+def use_mfma() -> bool:
+    """FOSVOS_RESNET_MFMA=0 keeps every layer on the vector-ALU kernel (A/B runs)."""
+    return os.environ.get("FOSVOS_RESNET_MFMA", "1") != "0"
 
-    def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], what: str) -> None:
+
+class _Conv:
+    """One packed conv (+ folded BatchNorm).  3x3 stride-1 layers whose channel counts fit the MFMA implicit GEMM
+    (Ci % 32 == 0, Co % 64 == 0) take that path (kind 1), everything else the vector-ALU direct conv (kind 0)."""
+    __slots__ = ("packed", "bias", "ci", "co", "k", "stride", "kind")
+
+    def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], what: str, allow_mfma: bool = True) -> None:
         k = conv.kernel_size[0]
         if (conv.kernel_size not in ((1, 1), (3, 3)) or conv.stride not in ((1, 1), (2, 2)) or conv.dilation != (1, 1)
                 or conv.groups != 1 or conv.padding != (k // 2, k // 2)):
@@ -31,15 +38,28 @@ class _Conv:
             raise NotImplementedError(f"{what}: BatchNorm without affine running statistics cannot be folded")
         self.ci, self.co, self.k, self.stride = conv.in_channels, conv.out_channels, k, conv.stride[0]
         bnp = None if bn is None else (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
-        self.packed, self.bias = ops.pack_conv2d_bn(conv.weight.detach(), None if conv.bias is None else conv.bias.detach(),
-                                                    bnp)
+        cb = None if conv.bias is None else conv.bias.detach()
+        # (16 output channels is the side_prep shape: the MFMA path has a 16-wide tile with an fp32 store for it)
+        self.kind = int(allow_mfma and use_mfma() and k == 3 and self.stride == 1 and self.ci % 32 == 0
+                        and (self.co % 64 == 0 or self.co == 16))
+        if self.kind:
+            folded, self.bias = ops.fold_conv_bn(conv.weight.detach(), cb, bnp)
+            self.packed, _ = ops.pack_conv3x3_weights(folded, want_fwd=True, want_dgrad=False)
+        else:
+            self.packed, self.bias = ops.pack_conv2d_bn(conv.weight.detach(), cb, bnp)
 
     def __call__(self, x: torch.Tensor, relu: bool, addend: Optional[torch.Tensor] = None,
                  out_f32: bool = False) -> torch.Tensor:
+        if self.kind and self.co == 16:
+            if addend is not None:
+                raise NotImplementedError("16-channel MFMA conv has no residual epilogue")
+            return ops.conv3x3_fwd(x, self.packed, self.bias, self.ci, self.co, relu=relu, out_f32=out_f32)
+        if self.kind:
+            return ops.conv3x3_fwd_add(x, self.packed, self.bias, self.ci, self.co, relu, addend)
         return ops.conv2d_fwd(x, self.packed, self.bias, self.ci, self.co, self.k, self.stride, relu, addend, out_f32)
 
     def desc(self) -> Conv2dDesc:
-        return Conv2dDesc(self.packed.data_ptr(), self.bias.data_ptr(), self.ci, self.co, self.k, self.stride)
+        return Conv2dDesc(self.packed.data_ptr(), self.bias.data_ptr(), self.ci, self.co, self.k, self.stride, self.kind)
 
 
 class _Block:
@@ -52,7 +72,7 @@ class _Block:
         self.convs = [_Conv(c, b, f"{what}.conv{i + 1}") for i, (c, b) in enumerate(pairs)]
         self.down = None
         if blk.downsample is not None:
-            self.down = _Conv(blk.downsample[0], blk.downsample[1], f"{what}.downsample")
+            self.down = _Conv(blk.downsample[0], blk.downsample[1], f"{what}.downsample", allow_mfma=False)
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         res = x if self.down is None else self.down(x, relu=False)
@@ -70,7 +90,7 @@ class ResnetPlan:
 
     @staticmethod
     def _signature(net: nn.Module):
-        return tuple((t.data_ptr(), t._version) for t in list(net.parameters()) + list(net.buffers()))
+        return (use_mfma(),) + tuple((t.data_ptr(), t._version) for t in list(net.parameters()) + list(net.buffers()))
 
     def refresh(self, net: nn.Module) -> None:
         sig = self._signature(net)

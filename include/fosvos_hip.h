@@ -108,6 +108,12 @@ int fosvos_conv3x3_fwd(const uint16_t *x, const uint16_t *w_packed, const float 
                        int Ci, int Co, unsigned flags, void *workspace, size_t workspace_bytes, int device,
                        void *stream);
 
+/* The residual form: y = act(conv3x3(x) + bias + addend), ReLU (FOSVOS_CONV_RELU) applied AFTER the add; addend is bf16
+ * [N,H,W,Co] (NULL: same as fosvos_conv3x3_fwd).  Co % 64 == 0.
+ * replaces: conv2 + bn2 + `out += residual` + relu of torchvision's BasicBlock (src/networks/osvos_resnet.py:203-214). */
+int fosvos_conv3x3_fwd_add(const uint16_t *x, const uint16_t *w_packed, const float *bias, const uint16_t *addend,
+                           uint16_t *y, int N, int H, int W, int Ci, int Co, unsigned flags, void *workspace,
+                           size_t workspace_bytes, int device, void *stream);
 /* fosvos_conv3x3_fwd plus MaxPool2d(2,2,ceil_mode=True) of its output in the same launch (the last conv of a VGG stage
  * feeds both the side branch and the pool, src/networks/osvos_vgg.py:90-93): y as above (bf16, Co % 64 == 0),
  * y_pool = [N, ceil(H/2), ceil(W/2), Co] bf16.  Saves the pool kernel's re-read of y. */
@@ -218,6 +224,11 @@ int fosvos_sgd_momentum_step(const fosvos_sgd_entry *table, int n_tensors, int64
  * (v_dot2c_f32_bf16, fp32 accumulate) with any channel counts - these layers are too thin for the MFMA path.
  * replaces: nn.Conv2d + nn.BatchNorm2d (+ residual add) + nn.ReLU of torchvision's BasicBlock / Bottleneck as wired by
  *           src/networks/osvos_resnet.py:91-121,187-216, and the side_prep convs of :135. */
+/* The fold alone (fp32 OIHW in, fp32 OIHW out, bias_out[Co]): for 3x3 stride-1 layers whose channel counts fit the MFMA
+ * path (Ci % 32 == 0, Co % 64 == 0), which then go through fosvos_pack_conv3x3_weights and fosvos_conv3x3_fwd[_add]. */
+int fosvos_fold_conv_bn(const float *w_oihw, int Co, int Ci, int k, const float *conv_bias, const float *bn_weight,
+                        const float *bn_bias, const float *bn_mean, const float *bn_var, float eps, float *w_folded,
+                        float *bias_out, int device, void *stream);
 size_t fosvos_conv2d_packed_dwords(int out_ch, int in_ch, int k);
 size_t fosvos_conv2d_bias_elems(int out_ch);
 int fosvos_pack_conv2d_bn(const float *w_oihw, int Co, int Ci, int k /* 1 or 3 */, const float *conv_bias,
@@ -261,9 +272,10 @@ int fosvos_deconv_head_fwd(const float *const side[4], const int hs[4], const in
  * calls above; `blocks` is a host array listing the blocks stage after stage.
  * replaces: OSVOS_RESNET.forward (src/networks/osvos_resnet.py:42-68) as driven from Python. */
 typedef struct fosvos_conv2d_desc {
-    const uint32_t *w_packed;
-    const float *bias;
+    const void *w_packed;       /* kind 0: fosvos_pack_conv2d_bn image; kind 1: fosvos_pack_conv3x3_weights forward image */
+    const float *bias;          /* kind 0: fosvos_conv2d_bias_elems floats; kind 1: Co floats */
     int Ci, Co, k, stride;
+    int kind;                   /* 0 = vector-ALU direct conv, 1 = MFMA implicit GEMM (3x3, stride 1, Ci % 32 == 0, Co % 64 == 0) */
 } fosvos_conv2d_desc;
 typedef struct fosvos_resnet_block {
     fosvos_conv2d_desc conv[3]; /* conv+bn(+relu) chain; the last one adds the residual before its ReLU */

@@ -84,6 +84,43 @@ def test_conv2d_matches_torch(ci, co, k, stride, relu, with_bn, with_add, f32):
     assert (got - ref).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("ci,co,hw,relu,with_add", [
+    (64, 64, (40, 56), True, True),       # BasicBlock conv2 + residual
+    (64, 64, (40, 56), True, False),      # BasicBlock conv1
+    (128, 128, (17, 30), True, True),     # small map: split-K epilogue kernel
+    (32, 64, (33, 47), False, True),
+    (256, 256, (9, 15), True, True),
+])
+def test_mfma_residual_conv_matches_torch(ci, co, hw, relu, with_add):
+    """The MFMA implicit GEMM in its residual form (fosvos_conv3x3_fwd_add) with BatchNorm folded by fosvos_fold_conv_bn:
+    relu(conv + bias + addend).  The conv result is rounded to bf16 before the add (the tile is staged in bf16), hence
+    2 x 2^-8 of the output scale."""
+    from fosvos_hip import ops
+    g = torch.Generator().manual_seed(ci + co + hw[0])
+    n, (h, w) = 2, hw
+    x = _bf(torch.randn(n, ci, h, w, generator=g))
+    wt = torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (ci * 9)) ** 0.5
+    bn = _bn_params(co, g)
+    folded, bias = ops.fold_conv_bn(wt.to(DEV), None, tuple(t.to(DEV) for t in bn[:4]) + (bn[4],))
+    s = bn[0] / torch.sqrt(bn[3] + bn[4])
+    assert torch.allclose(folded.cpu(), wt * s.view(-1, 1, 1, 1), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(bias.cpu(), bn[1] - bn[2] * s, rtol=1e-6, atol=1e-6)
+    packed, none = ops.pack_conv3x3_weights(folded, want_fwd=True, want_dgrad=False)
+    assert none is None
+    ref = F.conv2d(x, _bf(folded.cpu()), bias.cpu(), padding=1)
+    add = None
+    if with_add:
+        add = _bf(torch.randn(ref.shape, generator=g))
+        ref = ref + add
+    if relu:
+        ref = F.relu(ref)
+    y = ops.conv3x3_fwd_add(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV), packed, bias, ci, co, relu,
+                            None if add is None else add.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV))
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() <= 2.0 ** -7 * max(ref.abs().max().item(), 1.0) + 1e-5
+
+
 def test_first_conv_and_pool_match_torch():
     from fosvos_hip import ops
     g = torch.Generator().manual_seed(3)
@@ -171,11 +208,30 @@ def test_network_matches_oracle(version, e, hw):
     _check_net(net, sd, x)
 
 
+def test_wide_net_on_the_vector_alu_path_only(monkeypatch):
+    """FOSVOS_RESNET_MFMA=0: the 64..512-channel layers of the full-width net on the direct kernel (the default routes
+    them to the MFMA implicit GEMM)."""
+    from networks.osvos_resnet import OSVOS_RESNET
+    from oracle import osvos_resnet_ref as R
+    monkeypatch.setenv("FOSVOS_RESNET_MFMA", "0")
+    sd = R.make_state_dict(18, 0, seed=21)
+    net = OSVOS_RESNET(pretrained=False, version=18, scale_down_exponent=0)
+    net.load_state_dict(sd)
+    x = 50.0 * torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(9))
+    outs, _ = _check_net(net, sd, x)
+    assert all(b.convs[0].kind == 0 for st in net._plan.stages for b in st)
+    monkeypatch.setenv("FOSVOS_RESNET_MFMA", "1")
+    outs2 = net(x.to(DEV))                                  # same weights, plan rebuilt with the MFMA layers
+    assert any(b.convs[0].kind == 1 for st in net._plan.stages for b in st)
+    ref = R.forward(sd, x)[-1]
+    assert (outs2[-1].cpu() - ref).abs().max().item() <= 3e-2 * ref.abs().max().item()
+
+
 def test_native_loop_equals_the_op_by_op_loop():
     from fosvos_hip import resnet_engine
     from networks.osvos_resnet import OSVOS_RESNET
     from oracle import osvos_resnet_ref as R
-    for version, e, hw in ((18, 1, (65, 99)), (34, 3, (128, 160))):
+    for version, e, hw in ((18, 1, (65, 99)), (34, 3, (128, 160)), (18, 0, (64, 80))):
         net = OSVOS_RESNET(pretrained=False, version=version, scale_down_exponent=e)
         net.load_state_dict(R.make_state_dict(version, e, seed=3))
         net = net.to(DEV).eval()
