@@ -25,6 +25,9 @@ namespace {
 
 // internal epilogue flag (never crosses the ABI): ReLU after the addend has been added - the residual form
 constexpr unsigned kReluAfterAdd = 0x100u;
+// ... and: keep only the even (row, column) pixels, stored as [N,(H-1)/2+1,(W-1)/2+1,Cout] - a stride-2 conv computed at
+// stride 1 (4x the arithmetic of a strided kernel, still several times faster than the vector-ALU conv at these widths)
+constexpr unsigned kSubsample2 = 0x200u;
 
 struct ConvArgs {
     const uint16_t *x;         // [N,H,W,Cin] bf16, Cin % 32 == 0
@@ -422,7 +425,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))
             const int pix = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
             const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
             if (gy >= H || gx >= W) continue;
-            const int64_t off = (((int64_t)n * H + gy) * W + gx) * a.Cout + n0 + cg * 8;
+            int64_t off = (((int64_t)n * H + gy) * W + gx) * a.Cout + n0 + cg * 8;
+            if (a.flags & kSubsample2) {
+                if ((gy | gx) & 1) continue;
+                off = (((int64_t)n * ((H + 1) >> 1) + (gy >> 1)) * ((W + 1) >> 1) + (gx >> 1)) * a.Cout + n0 + cg * 8;
+            }
             *reinterpret_cast<uint4 *>(yo + off) = *reinterpret_cast<const uint4 *>(sO + pix * T::OUT_LD + cg * 8);
         }
     }
@@ -463,7 +470,15 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int64
     const int64_t plane = (int64_t)a.N * a.H * a.W * a.Cout;
     for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
         const int g = (int)(i % groups);
-        const int64_t off = i * 8;
+        int64_t off = i * 8;  // where the sums are read; the result goes to i * 8
+        if (a.flags & kSubsample2) {
+            const int Ho = (a.H + 1) >> 1, Wo = (a.W + 1) >> 1;
+            int64_t pq = i / groups;
+            const int ox = (int)(pq % Wo);
+            pq /= Wo;
+            const int oy = (int)(pq % Ho), n = (int)(pq / Ho);
+            off = (((int64_t)n * a.H + 2 * oy) * a.W + 2 * ox) * a.Cout + g * 8;
+        }
         float f[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = 0.f;
@@ -520,7 +535,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int64
                 for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
             }
         }
-        *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(a.y) + off) = pack8(f);
+        *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(a.y) + i * 8) = pack8(f);
     }
 }
 
@@ -599,7 +614,8 @@ int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st) {
                        T::LDS_BYTES, st, a);
     FOSVOS_LAUNCH_CHECK();
     if (plan.k_splits > 1) {
-        const int64_t total8 = (int64_t)a.N * a.H * a.W * (a.Cout / 8);
+        const int64_t total8 = (a.flags & kSubsample2) ? (int64_t)a.N * ((a.H + 1) >> 1) * ((a.W + 1) >> 1) * (a.Cout / 8)
+                                                       : (int64_t)a.N * a.H * a.W * (a.Cout / 8);
         int64_t g = cdiv(total8, 256);
         if (g > 4096) g = 4096;
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)g), dim3(256), 0, st, a, total8);
@@ -676,6 +692,20 @@ extern "C" int fosvos_conv3x3_fwd_add(const uint16_t *x, const uint16_t *w_packe
     a.x = x; a.w = w_packed; a.bias = bias; a.relu_src = nullptr; a.addend = addend; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Cin = roundup(Ci, 32); a.Cout = Co; a.Co_pad = roundup(Co, 16);
     a.flags = (flags & FOSVOS_CONV_RELU) ? kReluAfterAdd : 0u;
+    return dispatch(a, Ci, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int fosvos_conv3x3_s2_fwd(const uint16_t *x, const uint16_t *w_packed, const float *bias, uint16_t *y, int N,
+                                     int H, int W, int Ci, int Co, unsigned flags, void *workspace, size_t workspace_bytes,
+                                     int device, void *stream) {
+    if (int rc = check_common(x, w_packed, y, N, H, W, Ci, Co, "conv3x3_s2_fwd")) return rc;
+    FOSVOS_REQUIRE((flags & ~FOSVOS_CONV_RELU) == 0, FOSVOS_E_ARG, "conv3x3_s2_fwd: unknown flags 0x%x", flags);
+    FOSVOS_REQUIRE(Co % 64 == 0, FOSVOS_E_SHAPE, "conv3x3_s2_fwd: Co=%d must be a multiple of 64", Co);
+    FOSVOS_ENTER(device);
+    ConvArgs a{};
+    a.x = x; a.w = w_packed; a.bias = bias; a.relu_src = nullptr; a.addend = nullptr; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = roundup(Ci, 32); a.Cout = Co; a.Co_pad = roundup(Co, 16);
+    a.flags = flags | kSubsample2;
     return dispatch(a, Ci, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

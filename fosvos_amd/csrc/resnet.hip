@@ -679,7 +679,9 @@ int resnet_layout(const fosvos_resnet_net *net, int N, int H, int W, ResnetLayou
                 FOSVOS_REQUIRE(c.w_packed && c.bias && c.Ci == y.c, FOSVOS_E_SHAPE,
                                "resnet: block %d conv %d takes %d channels, its input has %d", b, q + 1, c.Ci, y.c);
                 if (c.kind == 1) {
-                    FOSVOS_REQUIRE(c.k == 3 && c.stride == 1 && c.Ci % 32 == 0 && c.Co % 64 == 0, FOSVOS_E_SHAPE,
+                    FOSVOS_REQUIRE(c.k == 3 && (c.stride == 1 || (c.stride == 2 && q < blk.n_convs - 1)) && c.Ci % 32 == 0 &&
+                                       c.Co % 64 == 0,
+                                   FOSVOS_E_SHAPE,
                                    "resnet: block %d conv %d (%d -> %d, k %d, stride %d) does not fit the MFMA path", b, q + 1,
                                    c.Ci, c.Co, c.k, c.stride);
                     ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, y.h, y.w, c.Ci, c.Co));
@@ -776,7 +778,11 @@ extern "C" int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *
                 const bool last = q == blk.n_convs - 1;
                 const int out = other(in, res, last ? -1 : cur);  // (the block input stays live until the residual is taken)
                 const uint16_t *add = last ? slot[res] : nullptr;
-                const int rc = c.kind == 1
+                const int rc = c.kind == 1 && c.stride == 2
+                                   ? fosvos_conv3x3_s2_fwd(slot[in], reinterpret_cast<const uint16_t *>(c.w_packed), c.bias, slot[out],
+                                                           N, ih, iw, c.Ci, c.Co, FOSVOS_CONV_RELU, base + L.ws_off, L.ws_bytes,
+                                                           device, stream)
+                               : c.kind == 1
                                    ? fosvos_conv3x3_fwd_add(slot[in], reinterpret_cast<const uint16_t *>(c.w_packed), c.bias, add,
                                                             slot[out], N, ih, iw, c.Ci, c.Co, FOSVOS_CONV_RELU, base + L.ws_off,
                                                             L.ws_bytes, device, stream)

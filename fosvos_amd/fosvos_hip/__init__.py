@@ -117,6 +117,8 @@ SIGNATURES = {
                                  c_int, c_void_p]),
     "fosvos_cbce_workspace_bytes": (c_size_t, [c_int64]),
     "fosvos_sgd_momentum_step": (c_int, [c_void_p, c_int, c_int64, c_float, c_int, c_int, c_void_p]),
+    "fosvos_conv3x3_s2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_uint,
+                                      c_void_p, c_size_t, c_int, c_void_p]),
     "fosvos_conv3x3_fwd_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                        c_uint, c_void_p, c_size_t, c_int, c_void_p]),
     "fosvos_fold_conv_bn": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -513,6 +513,29 @@ def conv3x3_fwd_add(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor,
     return y
 
 
+def conv3x3_s2_fwd(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, ci: int, co: int,
+                   relu: bool = True) -> torch.Tensor:
+    """Stride-2 conv3x3 (pad 1) on the MFMA path: [N,H,W,ci] -> [N,(H-1)//2+1,(W-1)//2+1,co], bf16 NHWC."""
+    _need(x, _BF16, "conv3x3_s2_fwd x"); _need(w_packed, _BF16, "conv3x3_s2_fwd packed weight")
+    _need(bias, _F32, "conv3x3_s2_fwd bias")
+    n, h, wd, cx = x.shape
+    L = lib()
+    if cx != ci or ci % 32 or co % 64:
+        raise ValueError(f"conv3x3_s2_fwd: x has {cx} channels for Ci={ci}, Co={co} (Ci % 32 == 0, Co % 64 == 0)")
+    if w_packed.numel() != L.fosvos_packed_weight_elems(co, ci) or bias.numel() != co:
+        raise ValueError("conv3x3_s2_fwd: packed weight / bias size does not match (Co, Ci)")
+    ho, wo = (h - 1) // 2 + 1, (wd - 1) // 2 + 1
+    y = torch.empty((n, ho, wo, co), dtype=_BF16, device=x.device)
+    ws, wsn = _WS.get(L.fosvos_conv3x3_workspace_bytes(n, h, wd, ci, co), x.device)
+    dev, st = _ctx(x)
+    t0 = _pb()
+    check(L.fosvos_conv3x3_s2_fwd(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), n, h, wd, ci, co,
+                                  CONV_RELU if relu else 0, ws, wsn, dev, st), "conv3x3_s2_fwd")
+    _pe(t0, f"mfma3x3s2 {ci}->{co} @{ho}x{wo}" if _PROF is not None and _PROF.detail else "mfma3x3s2",
+        2.0 * n * ho * wo * 9 * ci * co, 2 * (x.numel() + y.numel()))
+    return y
+
+
 def conv_out_size(h: int, k: int, stride: int) -> int:
     return (h + 2 * (k // 2) - k) // stride + 1
 

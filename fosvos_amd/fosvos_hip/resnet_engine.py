@@ -40,8 +40,9 @@ class _Conv:
         bnp = None if bn is None else (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
         cb = None if conv.bias is None else conv.bias.detach()
         # (16 output channels is the side_prep shape: the MFMA path has a 16-wide tile with an fp32 store for it)
-        self.kind = int(allow_mfma and use_mfma() and k == 3 and self.stride == 1 and self.ci % 32 == 0
-                        and (self.co % 64 == 0 or self.co == 16))
+        # stride 2 runs there too, with a subsampling store (fosvos_conv3x3_s2_fwd)
+        self.kind = int(allow_mfma and use_mfma() and k == 3 and self.ci % 32 == 0
+                        and (self.co % 64 == 0 or (self.co == 16 and self.stride == 1)))
         if self.kind:
             folded, self.bias = ops.fold_conv_bn(conv.weight.detach(), cb, bnp)
             self.packed, _ = ops.pack_conv3x3_weights(folded, want_fwd=True, want_dgrad=False)
@@ -54,6 +55,10 @@ class _Conv:
             if addend is not None:
                 raise NotImplementedError("16-channel MFMA conv has no residual epilogue")
             return ops.conv3x3_fwd(x, self.packed, self.bias, self.ci, self.co, relu=relu, out_f32=out_f32)
+        if self.kind and self.stride == 2:
+            if addend is not None:
+                raise NotImplementedError("stride-2 MFMA conv has no residual epilogue")
+            return ops.conv3x3_s2_fwd(x, self.packed, self.bias, self.ci, self.co, relu)
         if self.kind:
             return ops.conv3x3_fwd_add(x, self.packed, self.bias, self.ci, self.co, relu, addend)
         return ops.conv2d_fwd(x, self.packed, self.bias, self.ci, self.co, self.k, self.stride, relu, addend, out_f32)

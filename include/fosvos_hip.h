@@ -108,6 +108,12 @@ int fosvos_conv3x3_fwd(const uint16_t *x, const uint16_t *w_packed, const float 
                        int Ci, int Co, unsigned flags, void *workspace, size_t workspace_bytes, int device,
                        void *stream);
 
+/* Stride 2 (pad 1): y[N,(H-1)/2+1,(W-1)/2+1,Co] = act(conv3x3(x) + bias) at the even pixels.  Computed by the
+ * stride-1 MFMA kernel with a subsampling store: 4x the arithmetic of a strided kernel, which the MFMA rate more than pays
+ * for at Ci >= 32.  Co % 64 == 0; workspace as fosvos_conv3x3_fwd for the (N,H,W) INPUT shape.
+ * replaces: the stride-2 conv1 + bn1 + relu that opens ResNet stages 2-4 (src/networks/osvos_resnet.py:101-103). */
+int fosvos_conv3x3_s2_fwd(const uint16_t *x, const uint16_t *w_packed, const float *bias, uint16_t *y, int N, int H, int W,
+                          int Ci, int Co, unsigned flags, void *workspace, size_t workspace_bytes, int device, void *stream);
 /* The residual form: y = act(conv3x3(x) + bias + addend), ReLU (FOSVOS_CONV_RELU) applied AFTER the add; addend is bf16
  * [N,H,W,Co] (NULL: same as fosvos_conv3x3_fwd).  Co % 64 == 0.
  * replaces: conv2 + bn2 + `out += residual` + relu of torchvision's BasicBlock (src/networks/osvos_resnet.py:203-214). */
@@ -275,7 +281,8 @@ typedef struct fosvos_conv2d_desc {
     const void *w_packed;       /* kind 0: fosvos_pack_conv2d_bn image; kind 1: fosvos_pack_conv3x3_weights forward image */
     const float *bias;          /* kind 0: fosvos_conv2d_bias_elems floats; kind 1: Co floats */
     int Ci, Co, k, stride;
-    int kind;                   /* 0 = vector-ALU direct conv, 1 = MFMA implicit GEMM (3x3, stride 1, Ci % 32 == 0, Co % 64 == 0) */
+    int kind;                   /* 0 = vector-ALU direct conv, 1 = MFMA implicit GEMM (3x3, Ci % 32 == 0, Co % 64 == 0; Co = 16
+                                 * for side_prep; stride 2 through fosvos_conv3x3_s2_fwd) */
 } fosvos_conv2d_desc;
 typedef struct fosvos_resnet_block {
     fosvos_conv2d_desc conv[3]; /* conv+bn(+relu) chain; the last one adds the residual before its ReLU */

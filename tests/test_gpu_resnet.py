@@ -121,6 +121,25 @@ def test_mfma_residual_conv_matches_torch(ci, co, hw, relu, with_add):
     assert (got - ref).abs().max().item() <= 2.0 ** -7 * max(ref.abs().max().item(), 1.0) + 1e-5
 
 
+@pytest.mark.parametrize("ci,co,hw", [(64, 128, (40, 56)), (32, 64, (33, 47)), (128, 256, (17, 31)), (256, 512, (9, 14))])
+def test_mfma_stride2_conv_matches_torch(ci, co, hw):
+    """fosvos_conv3x3_s2_fwd: stride-2 conv as the stride-1 MFMA kernel with a subsampling store (odd sizes, and maps
+    small enough for the split-K epilogue)."""
+    from fosvos_hip import ops
+    g = torch.Generator().manual_seed(ci + co)
+    n, (h, w) = 2, hw
+    x = _bf(torch.randn(n, ci, h, w, generator=g))
+    wt = torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (ci * 9)) ** 0.5
+    bias = 0.1 * torch.randn(co, generator=g)
+    packed, _ = ops.pack_conv3x3_weights(wt.to(DEV), want_fwd=True, want_dgrad=False)
+    ref = F.relu(F.conv2d(x, _bf(wt), bias, stride=2, padding=1))
+    y = ops.conv3x3_s2_fwd(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV), packed, bias.to(DEV), ci, co, True)
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 2.0 ** -8 * max(ref.abs().max().item(), 1.0) + 1e-5
+
+
 def test_first_conv_and_pool_match_torch():
     from fosvos_hip import ops
     g = torch.Generator().manual_seed(3)
