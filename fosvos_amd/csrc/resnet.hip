@@ -14,6 +14,8 @@
 // Padded channels hold exact zeros everywhere (zero weights and bias), so no kernel ever masks a channel.
 #include "common.hpp"
 
+#include <mutex>
+
 using namespace fosvos;
 
 namespace {
@@ -654,7 +656,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // Arena: [first conv output][4 rotating activation slots of the largest block tensor][4 fp32 side maps]
 struct ResnetLayout {
-    size_t first_bytes, slot_bytes, side_off[4], side_bytes[4], ws_off, ws_bytes, total;
+    size_t first_bytes, slot_bytes, side_off[4], side_bytes[4], ws_off, ws_bytes, aux_ws_off, aux_ws_bytes, total;
     int hs[4], ws[4];
 };
 
@@ -666,7 +668,7 @@ int resnet_layout(const fosvos_resnet_net *net, int N, int H, int W, ResnetLayou
     L->first_bytes = align256(a.bytes(N));
     a.h = (a.h - 1) / 2 + 1;
     a.w = (a.w - 1) / 2 + 1;
-    size_t slot = a.bytes(N), ws = 0;
+    size_t slot = a.bytes(N), ws = 0, aux_ws = 0;
     int b = 0;
     for (int s = 0; s < 4; ++s) {
         FOSVOS_REQUIRE(net->blocks_per_stage[s] > 0, FOSVOS_E_ARG, "resnet: stage %d has no blocks", s);
@@ -708,7 +710,7 @@ int resnet_layout(const fosvos_resnet_net *net, int N, int H, int W, ResnetLayou
         if (sp.kind == 1) {
             FOSVOS_REQUIRE(sp.Ci % 32 == 0, FOSVOS_E_SHAPE, "resnet: side_prep %d (%d channels in) does not fit the MFMA path", s,
                            sp.Ci);
-            ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.h, a.w, sp.Ci, 16));
+            aux_ws = std::max(aux_ws, fosvos_conv3x3_workspace_bytes(N, a.h, a.w, sp.Ci, 16));
         }
         FOSVOS_REQUIRE(sp.Ci == a.c, FOSVOS_E_SHAPE, "resnet: side_prep %d expects %d input channels, the stage produces %d", s,
                        sp.Ci, a.c);
@@ -724,7 +726,9 @@ int resnet_layout(const fosvos_resnet_net *net, int N, int H, int W, ResnetLayou
     }
     L->ws_off = off;
     L->ws_bytes = align256(ws);
-    L->total = off + L->ws_bytes + 256;
+    L->aux_ws_off = off + L->ws_bytes;  // the side_prep convs may run beside the trunk (aux_stream): their own split-K slabs
+    L->aux_ws_bytes = align256(aux_ws);
+    L->total = L->aux_ws_off + L->aux_ws_bytes + 256;
     return 0;
 }
 
@@ -735,14 +739,43 @@ extern "C" size_t fosvos_resnet_arena_bytes(const fosvos_resnet_net *net, int N,
     return resnet_layout(net, N, H, W, &L) ? 0 : L.total;
 }
 
+namespace {
+constexpr int kResnetEvents = 12;  // 0: fork point, 1: downsample done, 2..5: side map s done, 6..9: side conv s may start
+struct ResnetEvents {
+    bool ready = false;
+    hipEvent_t ev[kResnetEvents];
+};
+ResnetEvents g_resnet_events[16];
+std::mutex g_resnet_events_mutex;
+
+int resnet_events(int device, hipEvent_t **out) {
+    FOSVOS_REQUIRE(device >= 0 && device < 16, FOSVOS_E_ARG, "resnet_forward: device %d", device);
+    std::lock_guard<std::mutex> lock(g_resnet_events_mutex);
+    ResnetEvents &p = g_resnet_events[device];
+    if (!p.ready) {
+        for (int i = 0; i < kResnetEvents; ++i) FOSVOS_HIP_CHECK(hipEventCreateWithFlags(&p.ev[i], hipEventDisableTiming));
+        p.ready = true;
+    }
+    *out = p.ev;
+    return 0;
+}
+}  // namespace
+
 extern "C" int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *frame, int N, int H, int W, void *arena,
                                      size_t arena_bytes, float *fused, float *const side_out[4], int device,
-                                     void *stream) {
+                                     void *stream, void *aux_stream) {
     ResnetLayout L;
     if (int rc = resnet_layout(net, N, H, W, &L)) return rc;
     FOSVOS_REQUIRE(frame && arena && fused, FOSVOS_E_ARG, "resnet_forward: null pointer");
     FOSVOS_REQUIRE(arena_bytes >= L.total, FOSVOS_E_WORKSPACE, "resnet_forward: arena of %zu bytes, %zu needed", arena_bytes,
                    L.total);
+    FOSVOS_ENTER(device);
+    hipStream_t sm = (hipStream_t)stream, sa = (hipStream_t)aux_stream;
+    const bool par = aux_stream != nullptr && aux_stream != stream;
+    hipEvent_t *ev = nullptr;
+    if (par) {
+        if (int rc = resnet_events(device, &ev)) return rc;
+    }
     char *base = reinterpret_cast<char *>(((uintptr_t)arena + 255) & ~(uintptr_t)255);
     uint16_t *first = reinterpret_cast<uint16_t *>(base);
     uint16_t *slot[4];
@@ -750,6 +783,16 @@ extern "C" int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *
     auto other = [](int a, int b, int c) {  // a slot that is none of a, b, c
         for (int q = 0; q < 4; ++q)
             if (q != a && q != b && q != c) return q;
+        return 0;
+    };
+    // a slot the auxiliary stream is still reading (the last stage output, under its side_prep conv): the trunk waits
+    // for that conv before the first kernel that writes the slot again
+    int busy_slot = -1, busy_ev = -1;
+    auto before_write = [&](int q) -> int {
+        if (par && q == busy_slot) {
+            FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[busy_ev], 0));
+            busy_slot = -1;
+        }
         return 0;
     };
 
@@ -767,16 +810,26 @@ extern "C" int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *
             const fosvos_resnet_block &blk = net->blocks[b];
             int res = cur;
             if (blk.has_down) {
+                // the 1x1 downsample conv of the residual branch runs beside conv1 (both read the block input)
                 res = other(cur, -1, -1);
-                if (int rc = fosvos_conv2d_fwd(slot[cur], reinterpret_cast<const uint32_t *>(blk.down.w_packed), blk.down.bias, nullptr, slot[res], N, h, w,
-                                               blk.down.Ci, blk.down.Co, blk.down.k, blk.down.stride, 0, device, stream))
+                if (int rc = before_write(res)) return rc;
+                if (par) {
+                    FOSVOS_HIP_CHECK(hipEventRecord(ev[0], sm));
+                    FOSVOS_HIP_CHECK(hipStreamWaitEvent(sa, ev[0], 0));
+                }
+                if (int rc = fosvos_conv2d_fwd(slot[cur], reinterpret_cast<const uint32_t *>(blk.down.w_packed), blk.down.bias,
+                                               nullptr, slot[res], N, h, w, blk.down.Ci, blk.down.Co, blk.down.k, blk.down.stride, 0,
+                                               device, par ? aux_stream : stream))
                     return rc;
+                if (par) FOSVOS_HIP_CHECK(hipEventRecord(ev[1], sa));
             }
             int in = cur, ih = h, iw = w;
             for (int q = 0; q < blk.n_convs; ++q) {
                 const fosvos_conv2d_desc &c = blk.conv[q];
                 const bool last = q == blk.n_convs - 1;
                 const int out = other(in, res, last ? -1 : cur);  // (the block input stays live until the residual is taken)
+                if (int rc = before_write(out)) return rc;
+                if (last && blk.has_down && par) FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[1], 0));
                 const uint16_t *add = last ? slot[res] : nullptr;
                 const int rc = c.kind == 1 && c.stride == 2
                                    ? fosvos_conv3x3_s2_fwd(slot[in], reinterpret_cast<const uint16_t *>(c.w_packed), c.bias, slot[out],
@@ -798,15 +851,34 @@ extern "C" int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *
             h = ih;
             w = iw;
         }
-        float *sm = reinterpret_cast<float *>(base + L.side_off[s]);
+        // side_prep of this stage: beside the next stage's blocks
+        float *smap = reinterpret_cast<float *>(base + L.side_off[s]);
         const fosvos_conv2d_desc &sp = net->side[s];
-        const int rc = sp.kind == 1 ? fosvos_conv3x3_fwd(slot[cur], reinterpret_cast<const uint16_t *>(sp.w_packed), sp.bias, sm, N, h,
-                                                         w, sp.Ci, 16, FOSVOS_CONV_OUT_F32, base + L.ws_off, L.ws_bytes, device,
-                                                         stream)
+        void *st = stream;
+        if (par) {
+            if (busy_slot >= 0) {  // one stage output at a time is tracked: retire the previous one first
+                FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[busy_ev], 0));
+                busy_slot = -1;
+            }
+            FOSVOS_HIP_CHECK(hipEventRecord(ev[6 + s], sm));
+            FOSVOS_HIP_CHECK(hipStreamWaitEvent(sa, ev[6 + s], 0));
+            st = aux_stream;
+        }
+        const int rc = sp.kind == 1 ? fosvos_conv3x3_fwd(slot[cur], reinterpret_cast<const uint16_t *>(sp.w_packed), sp.bias, smap, N,
+                                                         h, w, sp.Ci, 16, FOSVOS_CONV_OUT_F32, base + L.aux_ws_off, L.aux_ws_bytes,
+                                                         device, st)
                                     : fosvos_conv2d_fwd(slot[cur], reinterpret_cast<const uint32_t *>(sp.w_packed), sp.bias, nullptr,
-                                                        sm, N, h, w, sp.Ci, sp.Co, 3, 1, FOSVOS_CONV_OUT_F32, device, stream);
+                                                        smap, N, h, w, sp.Ci, sp.Co, 3, 1, FOSVOS_CONV_OUT_F32, device, st);
         if (rc) return rc;
-        side[s] = sm;
+        if (par) {
+            FOSVOS_HIP_CHECK(hipEventRecord(ev[2 + s], sa));
+            busy_slot = cur;
+            busy_ev = 2 + s;
+        }
+        side[s] = smap;
+    }
+    if (par) {
+        for (int s = 0; s < 4; ++s) FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[2 + s], 0));
     }
     return fosvos_deconv_head_fwd(side, L.hs, L.ws, net->stride, net->filt, net->filt1, net->dsn_w, net->dsn_b, net->fuse_b,
                                   fused, side_out, N, H, W, device, stream);

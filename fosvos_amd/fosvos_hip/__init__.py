@@ -140,7 +140,7 @@ SIGNATURES = {
                                        POINTER(c_void_p), c_int, c_int, c_int, c_int, c_void_p]),
     "fosvos_resnet_arena_bytes": (c_size_t, [POINTER(ResnetNet), c_int, c_int, c_int]),
     "fosvos_resnet_forward": (c_int, [POINTER(ResnetNet), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
-                                      POINTER(c_void_p), c_int, c_void_p]),
+                                      POINTER(c_void_p), c_int, c_void_p, c_void_p]),
     "fosvos_vgg_arena_bytes": (c_size_t, [c_int, c_int, c_int]),
     "fosvos_vgg_forward": (c_int, [POINTER(VggWeights), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                    POINTER(c_void_p), c_int, c_void_p]),

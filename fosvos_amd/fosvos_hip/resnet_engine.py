@@ -92,6 +92,7 @@ class ResnetPlan:
 
     def __init__(self) -> None:
         self.signature = None
+        self.aux = None  # the auxiliary HIP stream of the native loop (created on first use)
 
     @staticmethod
     def _signature(net: nn.Module):
@@ -208,7 +209,15 @@ def forward(net: nn.Module, plan: ResnetPlan, x: torch.Tensor) -> List[torch.Ten
         plan.arena = torch.empty(need, dtype=torch.uint8, device=x.device)
     outs = [torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device) for _ in range(5)]
     dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    aux = None
+    # FOSVOS_RESNET_AUX=1 issues the side_prep / downsample convs on a second stream beside the trunk.  Off by default:
+    # measured at 1080p it LOSES 0.09-0.12 ms per frame on every net (the ~20 cross-stream event waits cost more than the
+    # seven small kernels they take off the chain).
+    if os.environ.get("FOSVOS_RESNET_AUX", "0") == "1":
+        if plan.aux is None or plan.aux.device != x.device:
+            plan.aux = torch.cuda.Stream(device=x.device)
+        aux = plan.aux.cuda_stream
     check(L.fosvos_resnet_forward(ctypes.byref(plan.c_net), x.data_ptr(), n, h, w, plan.arena.data_ptr(),
                                   plan.arena.numel(), outs[4].data_ptr(), ptr_array4([o.data_ptr() for o in outs[:4]]), dev,
-                                  torch.cuda.current_stream(dev).cuda_stream), "resnet_forward")
+                                  torch.cuda.current_stream(dev).cuda_stream, aux), "resnet_forward")
     return outs

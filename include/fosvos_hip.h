@@ -303,9 +303,15 @@ typedef struct fosvos_resnet_net {
     const float *dsn_w, *dsn_b, *fuse_b;
 } fosvos_resnet_net;
 size_t fosvos_resnet_arena_bytes(const fosvos_resnet_net *net, int N, int H, int W);
-/* fused: [N,1,H,W] fp32; side_out: four [N,1,H,W] fp32 buffers or NULL. */
+/* fused: [N,1,H,W] fp32; side_out: four [N,1,H,W] fp32 buffers or NULL.
+ * aux_stream (a second hipStream_t of the same device, or NULL): when given, the kernels the trunk does not wait for
+ * right away - each stage's side_prep conv and the 1x1 downsample convs - are issued on it beside the trunk's chain
+ * (thin layers leave most of the chip idle), ordered by events (12 timing-disabled hipEvents per device, created on
+ * first use); the caller sees ordinary single-stream semantics on `stream`.  Measured on MI355X at 1920x1080 this
+ * costs 0.1 ms per frame more than it saves (cross-stream waits), so the shipped host passes NULL. */
 int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *frame, int N, int H, int W, void *arena,
-                          size_t arena_bytes, float *fused, float *const side_out[4], int device, void *stream);
+                          size_t arena_bytes, float *fused, float *const side_out[4], int device, void *stream,
+                          void *aux_stream);
 
 /* ---- whole-network entry points ------------------------------------------------------------------
  * The reference drives ~60 torch.nn calls per forward from Python (src/networks/osvos_vgg.py:61-83) and

@@ -258,9 +258,15 @@ def test_native_loop_equals_the_op_by_op_loop():
         a = net(x)
         b = resnet_engine.forward_ops(net, net._plan, x)
         a2 = net(x)                                          # the arena is reused
+        os.environ["FOSVOS_RESNET_AUX"] = "1"                # side_prep / downsample convs on the auxiliary stream
+        try:
+            a3 = net(x)
+            a4 = net(x)
+        finally:
+            del os.environ["FOSVOS_RESNET_AUX"]
         torch.cuda.synchronize()
-        for u, v, u2 in zip(a, b, a2):
-            assert torch.equal(u, v) and torch.equal(u, u2)
+        for u, v, u2, u3, u4 in zip(a, b, a2, a3, a4):
+            assert torch.equal(u, v) and torch.equal(u, u2) and torch.equal(u, u3) and torch.equal(u, u4)
 
 
 def test_weight_update_repacks_and_batch_of_one_equals_batch_rows():
