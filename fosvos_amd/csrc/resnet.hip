@@ -21,6 +21,7 @@ using namespace fosvos;
 namespace {
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t w, float acc) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, w), acc, false);
@@ -319,17 +320,22 @@ struct DeconvHeadArgs {
 // source pixel instead of once per output pixel and tap; the taps then read LDS (groups of f lanes share an address).
 constexpr int DH_PX = 8, DH_ROWS = 4, DH_COLS = 64 * DH_PX;
 constexpr int DH_NR = 3, DH_NC = DH_COLS / 4 + 2;  // window bound at the smallest stride (4)
+constexpr int DH_WIN = DH_NR * DH_NC;
+#define V4(v) f32x4{(v).x, (v).y, (v).z, (v).w}
 
 __global__ __launch_bounds__(256) void k_deconv_head(const DeconvHeadArgs g) {
-    __shared__ float4 sS[DH_NR * DH_NC * 4];
+    __shared__ f32x4 sS[DH_NR * DH_NC * 4];  // a true vector type: float4 (a struct) is scalarised and re-sliced into 4-byte reads
     __shared__ float sD[DH_NR * DH_NC];
     const int Xb = blockIdx.x * DH_COLS, Yb = blockIdx.y * DH_ROWS, n = blockIdx.z;
     const int X0 = Xb + threadIdx.x, Y = Yb + threadIdx.y;
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    float fused[DH_PX];
+    // two partial sums per pixel (even / odd channels): the operands of v_pk_fma_f32 are then register pairs as loaded,
+    // where one running sum per pixel made hipcc pair neighbouring PIXELS and shuffle their operands together (half of
+    // the kernel's 3900 vector instructions per wave were moves)
+    f32x2 fused[DH_PX];
     const float fb = g.fuse_b[0];
 #pragma unroll
-    for (int p = 0; p < DH_PX; ++p) fused[p] = fb;
+    for (int p = 0; p < DH_PX; ++p) fused[p] = f32x2{fb, 0.f};
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
         const int f = g.f[s], k = 2 * f, hs = g.hs[s], ws = g.ws[s], jstep = 64 / f;
@@ -338,10 +344,10 @@ __global__ __launch_bounds__(256) void k_deconv_head(const DeconvHeadArgs g) {
         const int i0 = yy / f, ky0 = yy - i0 * f, j0 = xx / f, kx0 = xx - j0 * f;
         // the filter of tap (a, b) sits at [ky0 + a f][kx0 + b f]; tap 0's is requested before the window is staged and
         // tap t + 1's while tap t is multiplied, so no tap waits out a global round trip
-        const float4 *fbase = reinterpret_cast<const float4 *>(g.filt[s]);
+        const f32x4 *fbase = reinterpret_cast<const f32x4 *>(g.filt[s]);
         const float *f1base = g.filt1[s];
         int fidx = ky0 * k + kx0;
-        float4 n0 = fbase[fidx * 4 + 0], n1 = fbase[fidx * 4 + 1], n2 = fbase[fidx * 4 + 2], n3 = fbase[fidx * 4 + 3];
+        f32x4 n0 = fbase[fidx * 4 + 0], n1 = fbase[fidx * 4 + 1], n2 = fbase[fidx * 4 + 2], n3 = fbase[fidx * 4 + 3];
         float nw = g.with_side_out ? f1base[fidx] : 0.f;
         __syncthreads();  // the previous scale's window has been consumed
         for (int idx = tid; idx < DH_NR * nc; idx += 256) {
@@ -361,10 +367,10 @@ __global__ __launch_bounds__(256) void k_deconv_head(const DeconvHeadArgs g) {
                     d = fmaf(v3.x, w3.x, d); d = fmaf(v3.y, w3.y, d); d = fmaf(v3.z, w3.z, d); d = fmaf(v3.w, w3.w, d);
                 }
             }
-            sS[idx * 4 + 0] = v0;
-            sS[idx * 4 + 1] = v1;
-            sS[idx * 4 + 2] = v2;
-            sS[idx * 4 + 3] = v3;
+            sS[0 * DH_WIN + idx] = V4(v0);  // channel-quad planes: neighbouring source pixels sit 16 B apart, so the taps' reads
+            sS[1 * DH_WIN + idx] = V4(v1);  // are conflict-free at any width hipcc splits them into (pixel-major, its 4-byte
+            sS[2 * DH_WIN + idx] = V4(v2);  // reads at a 64-B pitch spent half of all LDS cycles on bank conflicts)
+            sS[3 * DH_WIN + idx] = V4(v3);
             sD[idx] = d;
         }
         __syncthreads();
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(256) void k_deconv_head(const DeconvHeadArgs g) {
         for (int tap = 0; tap < 4; ++tap) {
             const int a = tap >> 1, b = tap & 1;
             const int r = i0 - a - r_lo;  // 0..2
-            const float4 f0 = n0, f1 = n1, f2 = n2, f3 = n3;
+            const f32x4 f0 = n0, f1 = n1, f2 = n2, f3 = n3;
             const float w1 = nw;
             if (tap < 3) {
                 const int ta = (tap + 1) >> 1, tb = (tap + 1) & 1;
@@ -389,12 +395,12 @@ __global__ __launch_bounds__(256) void k_deconv_head(const DeconvHeadArgs g) {
 #pragma unroll
             for (int p = 0; p < DH_PX; ++p) {
                 const int idx = base + p * jstep;
-                const float4 s0 = sS[idx * 4 + 0], s1 = sS[idx * 4 + 1], s2 = sS[idx * 4 + 2], s3 = sS[idx * 4 + 3];
-                float t = fused[p];
-                t = fmaf(s0.x, f0.x, t); t = fmaf(s0.y, f0.y, t); t = fmaf(s0.z, f0.z, t); t = fmaf(s0.w, f0.w, t);
-                t = fmaf(s1.x, f1.x, t); t = fmaf(s1.y, f1.y, t); t = fmaf(s1.z, f1.z, t); t = fmaf(s1.w, f1.w, t);
-                t = fmaf(s2.x, f2.x, t); t = fmaf(s2.y, f2.y, t); t = fmaf(s2.z, f2.z, t); t = fmaf(s2.w, f2.w, t);
-                t = fmaf(s3.x, f3.x, t); t = fmaf(s3.y, f3.y, t); t = fmaf(s3.z, f3.z, t); t = fmaf(s3.w, f3.w, t);
+                const f32x4 s0 = sS[idx], s1 = sS[DH_WIN + idx], s2 = sS[2 * DH_WIN + idx], s3 = sS[3 * DH_WIN + idx];
+                f32x2 t = fused[p];
+                t += s0.lo * f0.lo; t += s0.hi * f0.hi;
+                t += s1.lo * f1.lo; t += s1.hi * f1.hi;
+                t += s2.lo * f2.lo; t += s2.hi * f2.hi;
+                t += s3.lo * f3.lo; t += s3.hi * f3.hi;
                 fused[p] = t;
                 so[p] = fmaf(w1, sD[idx], so[p]);
             }
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(256) void k_deconv_head(const DeconvHeadArgs g) {
     if (Y >= g.H) return;
 #pragma unroll
     for (int p = 0; p < DH_PX; ++p)
-        if (X0 + 64 * p < g.W) g.fused[((int64_t)n * g.H + Y) * g.W + X0 + 64 * p] = fused[p];
+        if (X0 + 64 * p < g.W) g.fused[((int64_t)n * g.H + Y) * g.W + X0 + 64 * p] = fused[p][0] + fused[p][1];
 }
 
 // ------------------------------------------------------------------------------------------ launch planning
