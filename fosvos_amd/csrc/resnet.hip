@@ -433,9 +433,17 @@ ConvLaunch plan_conv2d(int64_t npix, int Cop, int cic) {
         pick = cob;
         if (cdiv(npix, 64) * nb >= 2048) break;
     }
+#ifdef FOSVOS_CONV2D_LAB
+    if (const char *e = getenv("FOSVOS_COB")) pick = atoi(e);
+#endif
     const int nb = (Cop + pick - 1) / pick;
     const int64_t waves = cdiv(npix, 64) * nb;
-    if (waves >= 2048 || cic < 2) return {pick, cdiv(npix, 256) * nb >= 1024 ? 256 : 64, 1};
+#ifdef FOSVOS_CONV2D_LAB
+    if (const char *e = getenv("FOSVOS_THREADS")) return {pick, atoi(e), 1};
+#endif
+    // (measured: at 2028 waves - 32 -> 32 channels on 135 x 240 - four slices cost 20 us against 15 unsliced; at 512 waves -
+    // 128 -> 128 on 34 x 60 - eight slices take 32 us against 83)
+    if (waves >= 1024 || cic < 2) return {pick, cdiv(npix, 256) * nb >= 1024 ? 256 : 64, 1};
     int slices = 2;
     while (slices < 8 && slices * 2 <= cic && waves * slices < 4096) slices *= 2;
     return {pick, 64, slices};
