@@ -28,6 +28,9 @@ constexpr unsigned kReluAfterAdd = 0x100u;
 // ... and: keep only the even (row, column) pixels, stored as [N,(H-1)/2+1,(W-1)/2+1,Cout] - a stride-2 conv computed at
 // stride 1 (4x the arithmetic of a strided kernel, still several times faster than the vector-ALU conv at these widths)
 constexpr unsigned kSubsample2 = 0x200u;
+// ... and: one launch per layer, no split-K.  The inference chain of the ResNet path pays ~5 us per dependent launch, more
+// than the slabs + epilogue kernel win on its small maps (measured at 1080p: -7 % per frame at exponent 1, -3 % at 2)
+constexpr unsigned kNoSplitK = 0x400u;
 
 struct ConvArgs {
     const uint16_t *x;         // [N,H,W,Cin] bf16, Cin % 32 == 0
@@ -634,7 +637,12 @@ int dispatch(ConvArgs a, int in_ch, void *workspace, size_t workspace_bytes, hip
     } else {
         FOSVOS_REQUIRE(!f32, FOSVOS_E_ARG, "conv3x3: fp32 output is only built for 16-channel outputs");
     }
-    const ConvPlan plan = make_plan(a.N, a.H, a.W, in_ch, a.Cout);
+    ConvPlan plan = make_plan(a.N, a.H, a.W, in_ch, a.Cout);
+    if (a.flags & kNoSplitK) {
+        plan.k_splits = 1;
+        plan.chunks_per_split = roundup(in_ch, 32) / 32;
+        plan.workspace_bytes = 0;
+    }
     if (plan.k_splits > 1) {
         FOSVOS_REQUIRE(workspace && workspace_bytes >= plan.workspace_bytes, FOSVOS_E_WORKSPACE,
                        "conv3x3: split-K needs %zu workspace bytes, got %zu", plan.workspace_bytes, workspace_bytes);
@@ -683,7 +691,6 @@ extern "C" int fosvos_conv3x3_fwd_add(const uint16_t *x, const uint16_t *w_packe
                                       const uint16_t *addend, uint16_t *y, int N, int H, int W, int Ci, int Co,
                                       unsigned flags, void *workspace, size_t workspace_bytes, int device,
                                       void *stream) {
-    if (!addend) return fosvos_conv3x3_fwd(x, w_packed, bias, y, N, H, W, Ci, Co, flags, workspace, workspace_bytes, device, stream);
     if (int rc = check_common(x, w_packed, y, N, H, W, Ci, Co, "conv3x3_fwd_add")) return rc;
     FOSVOS_REQUIRE((flags & ~FOSVOS_CONV_RELU) == 0, FOSVOS_E_ARG, "conv3x3_fwd_add: unknown flags 0x%x", flags);
     FOSVOS_REQUIRE(Co % 64 == 0, FOSVOS_E_SHAPE, "conv3x3_fwd_add: Co=%d must be a multiple of 64", Co);
@@ -691,7 +698,7 @@ extern "C" int fosvos_conv3x3_fwd_add(const uint16_t *x, const uint16_t *w_packe
     ConvArgs a{};
     a.x = x; a.w = w_packed; a.bias = bias; a.relu_src = nullptr; a.addend = addend; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Cin = roundup(Ci, 32); a.Cout = Co; a.Co_pad = roundup(Co, 16);
-    a.flags = (flags & FOSVOS_CONV_RELU) ? kReluAfterAdd : 0u;
+    a.flags = kNoSplitK | (addend ? ((flags & FOSVOS_CONV_RELU) ? kReluAfterAdd : 0u) : flags);
     return dispatch(a, Ci, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -705,7 +712,7 @@ extern "C" int fosvos_conv3x3_s2_fwd(const uint16_t *x, const uint16_t *w_packed
     ConvArgs a{};
     a.x = x; a.w = w_packed; a.bias = bias; a.relu_src = nullptr; a.addend = nullptr; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Cin = roundup(Ci, 32); a.Cout = Co; a.Co_pad = roundup(Co, 16);
-    a.flags = flags | kSubsample2;
+    a.flags = flags | kSubsample2 | kNoSplitK;
     return dispatch(a, Ci, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

@@ -700,7 +700,6 @@ int resnet_layout(const fosvos_resnet_net *net, int N, int H, int W, ResnetLayou
                                    FOSVOS_E_SHAPE,
                                    "resnet: block %d conv %d (%d -> %d, k %d, stride %d) does not fit the MFMA path", b, q + 1,
                                    c.Ci, c.Co, c.k, c.stride);
-                    ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, y.h, y.w, c.Ci, c.Co));
                 } else {
                     FOSVOS_REQUIRE(c.kind == 0, FOSVOS_E_ARG, "resnet: block %d conv %d has kind %d", b, q + 1, c.kind);
                 }

@@ -110,12 +110,13 @@ int fosvos_conv3x3_fwd(const uint16_t *x, const uint16_t *w_packed, const float 
 
 /* Stride 2 (pad 1): y[N,(H-1)/2+1,(W-1)/2+1,Co] = act(conv3x3(x) + bias) at the even pixels.  Computed by the
  * stride-1 MFMA kernel with a subsampling store: 4x the arithmetic of a strided kernel, which the MFMA rate more than pays
- * for at Ci >= 32.  Co % 64 == 0; workspace as fosvos_conv3x3_fwd for the (N,H,W) INPUT shape.
+ * for at Ci >= 32.  Co % 64 == 0; one launch, the workspace is not used.
  * replaces: the stride-2 conv1 + bn1 + relu that opens ResNet stages 2-4 (src/networks/osvos_resnet.py:101-103). */
 int fosvos_conv3x3_s2_fwd(const uint16_t *x, const uint16_t *w_packed, const float *bias, uint16_t *y, int N, int H, int W,
                           int Ci, int Co, unsigned flags, void *workspace, size_t workspace_bytes, int device, void *stream);
 /* The residual form: y = act(conv3x3(x) + bias + addend), ReLU (FOSVOS_CONV_RELU) applied AFTER the add; addend is bf16
- * [N,H,W,Co] (NULL: same as fosvos_conv3x3_fwd).  Co % 64 == 0.
+ * [N,H,W,Co] or NULL.  Co % 64 == 0.  Always ONE launch (no split-K, the workspace is not used): this is the inference
+ * form, whose chain of small dependent launches pays more for a second kernel than the split wins.
  * replaces: conv2 + bn2 + `out += residual` + relu of torchvision's BasicBlock (src/networks/osvos_resnet.py:203-214). */
 int fosvos_conv3x3_fwd_add(const uint16_t *x, const uint16_t *w_packed, const float *bias, const uint16_t *addend,
                            uint16_t *y, int N, int H, int W, int Ci, int Co, unsigned flags, void *workspace,
