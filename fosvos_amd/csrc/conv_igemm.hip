@@ -548,8 +548,10 @@ using TileMid = Tile<8, 16, 64, 2, 2>;    // 128 px x 64 ch
 using TileSmall = Tile<4, 16, 64, 2, 2>;  //  64 px x 64 ch
 using TileSide = Tile<8, 32, 16, 4, 1>;   // 256 px x 16 ch: side_prep at large maps
 using TileSideS = Tile<4, 16, 16, 4, 1>;  //  64 px x 16 ch: side_prep at small maps
+using TileHalf = Tile<8, 32, 32, 4, 1>;   // 256 px x 32 ch: the 32-channel layers of the thinned ResNets
+using TileHalfS = Tile<4, 16, 32, 4, 1>;  //  64 px x 32 ch: ... at small maps
 
-enum TileId { kBig, kMid, kSmall, kSide, kSideS };
+enum TileId { kBig, kMid, kSmall, kSide, kSideS, kHalf, kHalfS };
 
 struct ConvPlan {
     TileId tile;
@@ -574,6 +576,9 @@ ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
         // stream, which fills the second slot of each CU); below that the 128-pixel tile, 3 per CU
         if (blocks(8, 32, 64) >= kMinBlocks / 2) { p.tile = kBig; nb = blocks(8, 32, 64); }
         else { p.tile = kMid; nb = blocks(8, 16, 64); }
+    } else if (out_ch == 32) {
+        if (pixels >= 256 * 256) { p.tile = kHalf; nb = blocks(8, 32, 32); }
+        else { p.tile = kHalfS; nb = blocks(4, 16, 32); }
     } else {
         if (pixels >= 256 * 256) { p.tile = kSide; nb = blocks(8, 32, 16); }
         else { p.tile = kSideS; nb = blocks(4, 16, 16); }
@@ -629,8 +634,10 @@ int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st) {
 
 int dispatch(ConvArgs a, int in_ch, void *workspace, size_t workspace_bytes, hipStream_t st) {
     const bool f32 = (a.flags & FOSVOS_CONV_OUT_F32) != 0;
-    if (a.Cout % 64 != 0) {
-        FOSVOS_REQUIRE(a.Cout == 16, FOSVOS_E_SHAPE, "conv3x3: output channels must be 16 or a multiple of 64 (got %d)",
+    if (a.Cout == 32) {
+        FOSVOS_REQUIRE(!f32, FOSVOS_E_ARG, "conv3x3: fp32 output is only built for 16-channel outputs");
+    } else if (a.Cout % 64 != 0) {
+        FOSVOS_REQUIRE(a.Cout == 16, FOSVOS_E_SHAPE, "conv3x3: output channels must be 16, 32 or a multiple of 64 (got %d)",
                        a.Cout);
         FOSVOS_REQUIRE(a.relu_src == nullptr && a.addend == nullptr, FOSVOS_E_ARG,
                        "conv3x3: 16-channel output has no mask/add epilogue");
@@ -654,6 +661,8 @@ int dispatch(ConvArgs a, int in_ch, void *workspace, size_t workspace_bytes, hip
         case kSmall: return launch<TileSmall, false>(a, plan, st);
         case kSide: return f32 ? launch<TileSide, true>(a, plan, st) : launch<TileSide, false>(a, plan, st);
         case kSideS: return f32 ? launch<TileSideS, true>(a, plan, st) : launch<TileSideS, false>(a, plan, st);
+        case kHalf: return launch<TileHalf, false>(a, plan, st);
+        case kHalfS: return launch<TileHalfS, false>(a, plan, st);
     }
     return fail(FOSVOS_E_ARG, "conv3x3: bad plan");
 }
@@ -688,12 +697,16 @@ extern "C" int fosvos_conv3x3_fwd(const uint16_t *x, const uint16_t *w_packed, c
 }
 
 extern "C" int fosvos_conv3x3_fwd_add(const uint16_t *x, const uint16_t *w_packed, const float *bias,
-                                      const uint16_t *addend, uint16_t *y, int N, int H, int W, int Ci, int Co,
+                                      const uint16_t *addend, void *y, int N, int H, int W, int Ci, int Co,
                                       unsigned flags, void *workspace, size_t workspace_bytes, int device,
                                       void *stream) {
     if (int rc = check_common(x, w_packed, y, N, H, W, Ci, Co, "conv3x3_fwd_add")) return rc;
-    FOSVOS_REQUIRE((flags & ~FOSVOS_CONV_RELU) == 0, FOSVOS_E_ARG, "conv3x3_fwd_add: unknown flags 0x%x", flags);
-    FOSVOS_REQUIRE(Co % 64 == 0, FOSVOS_E_SHAPE, "conv3x3_fwd_add: Co=%d must be a multiple of 64", Co);
+    FOSVOS_REQUIRE((flags & ~(FOSVOS_CONV_RELU | FOSVOS_CONV_OUT_F32)) == 0, FOSVOS_E_ARG, "conv3x3_fwd_add: unknown flags 0x%x",
+                   flags);
+    FOSVOS_REQUIRE(Co % 64 == 0 || Co == 32 || (Co == 16 && !addend), FOSVOS_E_SHAPE,
+                   "conv3x3_fwd_add: Co=%d must be 32 or a multiple of 64 (16 without an addend)", Co);
+    FOSVOS_REQUIRE(!(flags & FOSVOS_CONV_OUT_F32) || (Co == 16 && !addend), FOSVOS_E_ARG,
+                   "conv3x3_fwd_add: fp32 output is the 16-channel side_prep form");
     FOSVOS_ENTER(device);
     ConvArgs a{};
     a.x = x; a.w = w_packed; a.bias = bias; a.relu_src = nullptr; a.addend = addend; a.y = y;
@@ -707,7 +720,7 @@ extern "C" int fosvos_conv3x3_s2_fwd(const uint16_t *x, const uint16_t *w_packed
                                      int device, void *stream) {
     if (int rc = check_common(x, w_packed, y, N, H, W, Ci, Co, "conv3x3_s2_fwd")) return rc;
     FOSVOS_REQUIRE((flags & ~FOSVOS_CONV_RELU) == 0, FOSVOS_E_ARG, "conv3x3_s2_fwd: unknown flags 0x%x", flags);
-    FOSVOS_REQUIRE(Co % 64 == 0, FOSVOS_E_SHAPE, "conv3x3_s2_fwd: Co=%d must be a multiple of 64", Co);
+    FOSVOS_REQUIRE(Co % 64 == 0 || Co == 32, FOSVOS_E_SHAPE, "conv3x3_s2_fwd: Co=%d must be 32 or a multiple of 64", Co);
     FOSVOS_ENTER(device);
     ConvArgs a{};
     a.x = x; a.w = w_packed; a.bias = bias; a.relu_src = nullptr; a.addend = nullptr; a.y = y;

@@ -696,7 +696,7 @@ int resnet_layout(const fosvos_resnet_net *net, int N, int H, int W, ResnetLayou
                                "resnet: block %d conv %d takes %d channels, its input has %d", b, q + 1, c.Ci, y.c);
                 if (c.kind == 1) {
                     FOSVOS_REQUIRE(c.k == 3 && (c.stride == 1 || (c.stride == 2 && q < blk.n_convs - 1)) && c.Ci % 32 == 0 &&
-                                       c.Co % 64 == 0,
+                                       (c.Co % 64 == 0 || c.Co == 32),
                                    FOSVOS_E_SHAPE,
                                    "resnet: block %d conv %d (%d -> %d, k %d, stride %d) does not fit the MFMA path", b, q + 1,
                                    c.Ci, c.Co, c.k, c.stride);
@@ -877,9 +877,9 @@ extern "C" int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *
             FOSVOS_HIP_CHECK(hipStreamWaitEvent(sa, ev[6 + s], 0));
             st = aux_stream;
         }
-        const int rc = sp.kind == 1 ? fosvos_conv3x3_fwd(slot[cur], reinterpret_cast<const uint16_t *>(sp.w_packed), sp.bias, smap, N,
-                                                         h, w, sp.Ci, 16, FOSVOS_CONV_OUT_F32, base + L.aux_ws_off, L.aux_ws_bytes,
-                                                         device, st)
+        const int rc = sp.kind == 1 ? fosvos_conv3x3_fwd_add(slot[cur], reinterpret_cast<const uint16_t *>(sp.w_packed), sp.bias,
+                                                             nullptr, smap, N, h, w, sp.Ci, 16, FOSVOS_CONV_OUT_F32,
+                                                             base + L.aux_ws_off, L.aux_ws_bytes, device, st)
                                     : fosvos_conv2d_fwd(slot[cur], reinterpret_cast<const uint32_t *>(sp.w_packed), sp.bias, nullptr,
                                                         smap, N, h, w, sp.Ci, sp.Co, 3, 1, FOSVOS_CONV_OUT_F32, device, st);
         if (rc) return rc;

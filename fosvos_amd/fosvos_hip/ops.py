@@ -488,17 +488,19 @@ def fold_conv_bn(w: torch.Tensor, conv_bias: Optional[torch.Tensor] = None, bn: 
 
 
 def conv3x3_fwd_add(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, ci: int, co: int, relu: bool = True,
-                    addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    addend: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
     """MFMA conv3x3 in its residual form: act(conv(x) + bias + addend), ReLU after the add; bf16 NHWC in and out."""
     _need(x, _BF16, "conv3x3_fwd_add x"); _need(w_packed, _BF16, "conv3x3_fwd_add packed weight")
     _need(bias, _F32, "conv3x3_fwd_add bias")
     n, h, wd, cx = x.shape
     L = lib()
-    if cx != ci or ci % 32 or co % 64:
-        raise ValueError(f"conv3x3_fwd_add: x has {cx} channels for Ci={ci}, Co={co} (Ci % 32 == 0, Co % 64 == 0)")
+    if cx != ci or ci % 32 or (co % 64 and co != 32 and not (co == 16 and addend is None)):
+        raise ValueError(f"conv3x3_fwd_add: x has {cx} channels for Ci={ci}, Co={co} (Ci % 32 == 0, Co = 32 or Co % 64 == 0)")
+    if out_f32 and co != 16:
+        raise ValueError("conv3x3_fwd_add: fp32 output is the 16-channel side_prep form")
     if w_packed.numel() != L.fosvos_packed_weight_elems(co, ci) or bias.numel() != co:
         raise ValueError("conv3x3_fwd_add: packed weight / bias size does not match (Co, Ci)")
-    y = torch.empty((n, h, wd, co), dtype=_BF16, device=x.device)
+    y = torch.empty((n, h, wd, co), dtype=_F32 if out_f32 else _BF16, device=x.device)
     if addend is not None:
         _need(addend, _BF16, "conv3x3_fwd_add addend")
         if addend.shape != y.shape:
@@ -507,7 +509,8 @@ def conv3x3_fwd_add(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor,
     dev, st = _ctx(x)
     t0 = _pb()
     check(L.fosvos_conv3x3_fwd_add(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), _p(addend), y.data_ptr(), n, h, wd, ci,
-                                   co, CONV_RELU if relu else 0, ws, wsn, dev, st), "conv3x3_fwd_add")
+                                   co, (CONV_RELU if relu else 0) | (CONV_OUT_F32 if out_f32 else 0), ws, wsn, dev, st),
+          "conv3x3_fwd_add")
     _pe(t0, f"mfma3x3s1 {ci}->{co} @{h}x{wd}" if _PROF is not None and _PROF.detail else "mfma3x3s1",
         2.0 * n * h * wd * 9 * ci * co, 2 * (x.numel() + y.numel()) + (2 * addend.numel() if addend is not None else 0))
     return y
@@ -520,8 +523,8 @@ def conv3x3_s2_fwd(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, 
     _need(bias, _F32, "conv3x3_s2_fwd bias")
     n, h, wd, cx = x.shape
     L = lib()
-    if cx != ci or ci % 32 or co % 64:
-        raise ValueError(f"conv3x3_s2_fwd: x has {cx} channels for Ci={ci}, Co={co} (Ci % 32 == 0, Co % 64 == 0)")
+    if cx != ci or ci % 32 or (co % 64 and co != 32):
+        raise ValueError(f"conv3x3_s2_fwd: x has {cx} channels for Ci={ci}, Co={co} (Ci % 32 == 0, Co = 32 or Co % 64 == 0)")
     if w_packed.numel() != L.fosvos_packed_weight_elems(co, ci) or bias.numel() != co:
         raise ValueError("conv3x3_s2_fwd: packed weight / bias size does not match (Co, Ci)")
     ho, wo = (h - 1) // 2 + 1, (wd - 1) // 2 + 1

@@ -26,7 +26,7 @@ def use_mfma() -> bool:
 
 class _Conv:
     """One packed conv (+ folded BatchNorm).  3x3 stride-1 layers whose channel counts fit the MFMA implicit GEMM
-    (Ci % 32 == 0, Co % 64 == 0) take that path (kind 1), everything else the vector-ALU direct conv (kind 0)."""
+    (Ci % 32 == 0; Co % 64 == 0 or Co = 32) take that path (kind 1), everything else the vector-ALU direct conv (kind 0)."""
     __slots__ = ("packed", "bias", "ci", "co", "k", "stride", "kind")
 
     def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], what: str, allow_mfma: bool = True) -> None:
@@ -42,7 +42,7 @@ class _Conv:
         # (16 output channels is the side_prep shape: the MFMA path has a 16-wide tile with an fp32 store for it)
         # stride 2 runs there too, with a subsampling store (fosvos_conv3x3_s2_fwd)
         self.kind = int(allow_mfma and use_mfma() and k == 3 and self.ci % 32 == 0
-                        and (self.co % 64 == 0 or (self.co == 16 and self.stride == 1)))
+                        and (self.co % 64 == 0 or self.co == 32 or (self.co == 16 and self.stride == 1)))
         if self.kind:
             folded, self.bias = ops.fold_conv_bn(conv.weight.detach(), cb, bnp)
             self.packed, _ = ops.pack_conv3x3_weights(folded, want_fwd=True, want_dgrad=False)
@@ -54,7 +54,7 @@ class _Conv:
         if self.kind and self.co == 16:
             if addend is not None:
                 raise NotImplementedError("16-channel MFMA conv has no residual epilogue")
-            return ops.conv3x3_fwd(x, self.packed, self.bias, self.ci, self.co, relu=relu, out_f32=out_f32)
+            return ops.conv3x3_fwd_add(x, self.packed, self.bias, self.ci, self.co, relu, None, out_f32=out_f32)
         if self.kind and self.stride == 2:
             if addend is not None:
                 raise NotImplementedError("stride-2 MFMA conv has no residual epilogue")

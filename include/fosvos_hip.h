@@ -110,16 +110,17 @@ int fosvos_conv3x3_fwd(const uint16_t *x, const uint16_t *w_packed, const float 
 
 /* Stride 2 (pad 1): y[N,(H-1)/2+1,(W-1)/2+1,Co] = act(conv3x3(x) + bias) at the even pixels.  Computed by the
  * stride-1 MFMA kernel with a subsampling store: 4x the arithmetic of a strided kernel, which the MFMA rate more than pays
- * for at Ci >= 32.  Co % 64 == 0; one launch, the workspace is not used.
+ * for at Ci >= 32.  Co % 64 == 0 or Co = 32; one launch, the workspace is not used.
  * replaces: the stride-2 conv1 + bn1 + relu that opens ResNet stages 2-4 (src/networks/osvos_resnet.py:101-103). */
 int fosvos_conv3x3_s2_fwd(const uint16_t *x, const uint16_t *w_packed, const float *bias, uint16_t *y, int N, int H, int W,
                           int Ci, int Co, unsigned flags, void *workspace, size_t workspace_bytes, int device, void *stream);
 /* The residual form: y = act(conv3x3(x) + bias + addend), ReLU (FOSVOS_CONV_RELU) applied AFTER the add; addend is bf16
- * [N,H,W,Co] or NULL.  Co % 64 == 0.  Always ONE launch (no split-K, the workspace is not used): this is the inference
+ * [N,H,W,Co] or NULL.  Co % 64 == 0 or Co = 32; without an addend also Co = 16, then optionally FOSVOS_CONV_OUT_F32 (the
+ * side_prep form).  Always ONE launch (no split-K, the workspace is not used): this is the inference
  * form, whose chain of small dependent launches pays more for a second kernel than the split wins.
  * replaces: conv2 + bn2 + `out += residual` + relu of torchvision's BasicBlock (src/networks/osvos_resnet.py:203-214). */
 int fosvos_conv3x3_fwd_add(const uint16_t *x, const uint16_t *w_packed, const float *bias, const uint16_t *addend,
-                           uint16_t *y, int N, int H, int W, int Ci, int Co, unsigned flags, void *workspace,
+                           void *y, int N, int H, int W, int Ci, int Co, unsigned flags, void *workspace,
                            size_t workspace_bytes, int device, void *stream);
 /* fosvos_conv3x3_fwd plus MaxPool2d(2,2,ceil_mode=True) of its output in the same launch (the last conv of a VGG stage
  * feeds both the side branch and the pool, src/networks/osvos_vgg.py:90-93): y as above (bf16, Co % 64 == 0),
@@ -282,7 +283,7 @@ typedef struct fosvos_conv2d_desc {
     const void *w_packed;       /* kind 0: fosvos_pack_conv2d_bn image; kind 1: fosvos_pack_conv3x3_weights forward image */
     const float *bias;          /* kind 0: fosvos_conv2d_bias_elems floats; kind 1: Co floats */
     int Ci, Co, k, stride;
-    int kind;                   /* 0 = vector-ALU direct conv, 1 = MFMA implicit GEMM (3x3, Ci % 32 == 0, Co % 64 == 0; Co = 16
+    int kind;                   /* 0 = vector-ALU direct conv, 1 = MFMA implicit GEMM (3x3, Ci % 32 == 0, Co % 64 == 0 or Co = 32; Co = 16
                                  * for side_prep; stride 2 through fosvos_conv3x3_s2_fwd) */
 } fosvos_conv2d_desc;
 typedef struct fosvos_resnet_block {

@@ -90,6 +90,9 @@ def test_conv2d_matches_torch(ci, co, k, stride, relu, with_bn, with_add, f32):
     (128, 128, (17, 30), True, True),     # small map: split-K epilogue kernel
     (32, 64, (33, 47), False, True),
     (256, 256, (9, 15), True, True),
+    (32, 32, (300, 260), True, True),     # the 32-wide tile (thinned nets), large-map variant
+    (32, 32, (33, 47), True, True),       # ... small-map variant
+    (64, 32, (20, 31), False, False),
 ])
 def test_mfma_residual_conv_matches_torch(ci, co, hw, relu, with_add):
     """The MFMA implicit GEMM in its residual form (fosvos_conv3x3_fwd_add) with BatchNorm folded by fosvos_fold_conv_bn:
@@ -121,7 +124,8 @@ def test_mfma_residual_conv_matches_torch(ci, co, hw, relu, with_add):
     assert (got - ref).abs().max().item() <= 2.0 ** -7 * max(ref.abs().max().item(), 1.0) + 1e-5
 
 
-@pytest.mark.parametrize("ci,co,hw", [(64, 128, (40, 56)), (32, 64, (33, 47)), (128, 256, (17, 31)), (256, 512, (9, 14))])
+@pytest.mark.parametrize("ci,co,hw", [(64, 128, (40, 56)), (32, 64, (33, 47)), (128, 256, (17, 31)), (256, 512, (9, 14)),
+                                      (32, 32, (41, 37))])
 def test_mfma_stride2_conv_matches_torch(ci, co, hw):
     """fosvos_conv3x3_s2_fwd: stride-2 conv as the stride-1 MFMA kernel with a subsampling store (odd sizes, and maps
     small enough for the split-K epilogue)."""
