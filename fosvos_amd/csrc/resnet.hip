@@ -78,7 +78,10 @@ __global__ void k_fold_conv_bn(const float *__restrict__ w, int Co, int per_co, 
     wo[i] = w[i] * (bn_w ? bn_w[co] / sqrtf(bn_v[co] + eps) : 1.f);
 }
 
-// First layer: [Co][3][7][7] fp32 -> [tap * 3 + ci][Cop] fp32 (the frame stays fp32, so do the weights).
+// First layer: [Co][3][7][7] fp32 -> two images.  (1) fp32 [tap * 3 + ci][Cop] for the vector-ALU kernel; (2) bf16 MFMA
+// fragments [k-step 6][k-group 4][channel NC][8] over K = 8 rows x 24 (a filter row is kx-major, channel-minor: 21 values +
+// 3 zeros; the 8th row is zeros), at float offset 147 * Cop + 64 of the same buffer, NC = Cop rounded up to 16.
+__host__ __device__ constexpr int f7_nc(int Cop) { return (Cop + 15) / 16 * 16; }
 __global__ void k_pack_conv7x7_bn(const float *__restrict__ w, int Co, const float *__restrict__ bn_w,
                                   const float *__restrict__ bn_b, const float *__restrict__ bn_m,
                                   const float *__restrict__ bn_v, float eps, float *__restrict__ wp,
@@ -88,6 +91,17 @@ __global__ void k_pack_conv7x7_bn(const float *__restrict__ w, int Co, const flo
         float b = 0.f;
         if (i < Co && bn_w) b = bn_b[i] - bn_m[i] * bn_w[i] / sqrtf(bn_v[i] + eps);
         bias_out[i] = b;
+    }
+    const int NC = f7_nc(Cop);
+    if (i < 6 * 4 * NC * 8) {
+        const int e = i & 7, n = (i >> 3) % NC, kgs = (i >> 3) / NC;  // kgs = k-step * 4 + k-group
+        const int k = kgs * 8 + e, ky = k / 24, j = k % 24;
+        float v = 0.f;
+        if (ky < 7 && j < 21 && n < Co) {
+            const float s = bn_w ? bn_w[n] / sqrtf(bn_v[n] + eps) : 1.f;
+            v = w[((int64_t)n * 3 + j % 3) * 49 + ky * 7 + j / 3] * s;
+        }
+        reinterpret_cast<uint16_t *>(wp + 147 * Cop + 64)[i] = f2bf(v);
     }
     if (i >= total) return;
     const int co = i % Cop, r = i / Cop;  // r = tap * 3 + ci
@@ -265,6 +279,81 @@ __global__ __launch_bounds__(256) void k_conv7x7s2_first(const float *__restrict
             if (relu) v[e] = fmaxf(v[e], 0.f);
         }
         y[pix * cop8 + co8] = pack8(v);
+    }
+}
+
+// The same layer on the matrix cores: frame and weights as bf16, K = 7 x 7 x 3 laid out as 8 rows x 24 (192 = 6 steps of
+// v_mfma_f32_16x16x32_bf16).  The patch is staged in LDS as bf16, pixel-major with the 3 channels interleaved, so the 21
+// values one output pixel needs from a patch row are contiguous and a lane's 8 consecutive k never leave a row; weights are
+// the row operand (a lane ends up with 4 consecutive channels of one pixel: an 8-byte store), all 6 x NFB weight fragments
+// stay in registers.  A workgroup owns 8 x 32 output pixels x all channels (Cop <= 64), a wave 2 rows of them.
+constexpr int F7_PITCH = 208;  // bf16 per patch row: 69 pixels x 3 channels = 207, +1
+
+template <int NFB>
+__global__ __launch_bounds__(256) void k_conv7x7s2_first_mfma(const float *__restrict__ frame, const uint4 *__restrict__ wimg,
+                                                              const float *__restrict__ bias, uint16_t *__restrict__ y,
+                                                              int H, int W, int Ho, int Wo, int tiles_x, int Cop, int relu) {
+    constexpr int ROWS = F7_PH + 1, NC = NFB * 16;
+    __shared__ __attribute__((aligned(16))) uint16_t sIn[ROWS * F7_PITCH + 8];
+    const int tile = blockIdx.x, n = blockIdx.z, tid = threadIdx.x;
+    const int oy0 = (tile / tiles_x) * F7_TH, ox0 = (tile % tiles_x) * F7_TW;
+    const int64_t plane = (int64_t)H * W;
+    const float *f0 = frame + (int64_t)n * 3 * plane;
+    for (int idx = tid; idx < 3 * F7_PH * F7_PW; idx += 256) {
+        const int ci = idx / (F7_PH * F7_PW), r = (idx / F7_PW) % F7_PH, c = idx % F7_PW;
+        const int iy = oy0 * 2 - 3 + r, ix = ox0 * 2 - 3 + c;
+        const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? f0[ci * plane + (int64_t)iy * W + ix] : 0.f;
+        sIn[r * F7_PITCH + c * 3 + ci] = f2bf(v);
+    }
+    // what only zero weights ever multiply must still be finite: the pad column of every row, the 8th filter row's patch
+    // row and the few elements a last lane reads past it
+    for (int idx = tid; idx < F7_PITCH + 8 + ROWS; idx += 256) {
+        if (idx < F7_PITCH + 8) sIn[F7_PH * F7_PITCH + idx] = 0;
+        else sIn[(idx - F7_PITCH - 8) * F7_PITCH + F7_PITCH - 1] = 0;
+    }
+    const int wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kg = lane >> 4;
+    bf16x8 wf[6][NFB];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int nf = 0; nf < NFB; ++nf) wf[ks][nf] = __builtin_bit_cast(bf16x8, wimg[(ks * 4 + kg) * NC + nf * 16 + l16]);
+    f32x4 acc[4][NFB];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NFB; ++nf) acc[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        const int k0 = ks * 32 + kg * 8, ky = k0 / 24, j0 = k0 % 24;
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const int ly = wave * 2 + (mf >> 1), lx = (mf & 1) * 16 + l16;
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(sIn + (2 * ly + ky) * F7_PITCH + 6 * lx + j0);
+            const uint4 av = make_uint4(p[0], p[1], p[2], p[3]);
+            const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+            for (int nf = 0; nf < NFB; ++nf)
+                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nf], a, acc[mf][nf], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        const int oy = oy0 + wave * 2 + (mf >> 1), ox = ox0 + (mf & 1) * 16 + l16;
+        if (oy >= Ho || ox >= Wo) continue;
+        uint16_t *yp = y + (((int64_t)n * Ho + oy) * Wo + ox) * Cop;
+#pragma unroll
+        for (int nf = 0; nf < NFB; ++nf) {
+            const int ch0 = nf * 16 + kg * 4;
+            if (ch0 >= Cop) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[mf][nf][r] + bias[ch0 + r];
+                if (relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            *reinterpret_cast<uint2 *>(yp + ch0) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        }
     }
 }
 
@@ -553,8 +642,10 @@ extern "C" int fosvos_conv2d_fwd(const uint16_t *x, const uint32_t *w_packed, co
     return 0;
 }
 
-extern "C" size_t fosvos_conv7x7_packed_elems(int out_ch) {
-    return out_ch > 0 ? (size_t)147 * roundup(out_ch, 8) + 64 : 0;
+extern "C" size_t fosvos_conv7x7_packed_elems(int out_ch) {  // fp32 image + slack, then the bf16 MFMA image (2 per float)
+    if (out_ch <= 0) return 0;
+    const int Cop = roundup(out_ch, 8);
+    return (size_t)147 * Cop + 64 + (size_t)6 * 4 * f7_nc(Cop) * 8 / 2;
 }
 
 extern "C" int fosvos_pack_conv7x7_bn(const float *w_oihw, int Co, const float *bn_weight, const float *bn_bias,
@@ -563,9 +654,9 @@ extern "C" int fosvos_pack_conv7x7_bn(const float *w_oihw, int Co, const float *
     FOSVOS_REQUIRE(w_oihw && w_packed && bias_out && Co > 0, FOSVOS_E_ARG, "pack_conv7x7_bn: bad argument");
     FOSVOS_REQUIRE(!bn_weight || (bn_bias && bn_mean && bn_var), FOSVOS_E_ARG, "pack_conv7x7_bn: partial BatchNorm");
     FOSVOS_ENTER(device);
-    const int Cop = roundup(Co, 8), total = (int)fosvos_conv7x7_packed_elems(Co);
+    const int Cop = roundup(Co, 8), total = 147 * Cop + 64;
     const int bias_len = (int)fosvos_conv2d_bias_elems(Co);
-    const int n = std::max(total, bias_len);
+    const int n = std::max(std::max(total, bias_len), 6 * 4 * f7_nc(Cop) * 8);
     hipLaunchKernelGGL(k_pack_conv7x7_bn, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, Co,
                        bn_weight, bn_bias, bn_mean, bn_var, eps, w_packed, bias_out, Cop, total, bias_len);
     FOSVOS_LAUNCH_CHECK();
@@ -576,14 +667,31 @@ extern "C" int fosvos_conv7x7s2_first_fwd(const float *frame, const float *w_pac
                                           int H, int W, int Co, unsigned flags, int device, void *stream) {
     FOSVOS_REQUIRE(frame && w_packed && bias && y, FOSVOS_E_ARG, "conv7x7s2_first_fwd: null pointer");
     FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && Co > 0, FOSVOS_E_ARG, "conv7x7s2_first_fwd: N=%d H=%d W=%d Co=%d", N, H, W, Co);
-    FOSVOS_REQUIRE((flags & ~(unsigned)FOSVOS_CONV_RELU) == 0, FOSVOS_E_ARG, "conv7x7s2_first_fwd: flags 0x%x", flags);
+    FOSVOS_REQUIRE((flags & ~(unsigned)(FOSVOS_CONV_RELU | FOSVOS_CONV_FP32_MATH)) == 0, FOSVOS_E_ARG,
+                   "conv7x7s2_first_fwd: flags 0x%x", flags);
     FOSVOS_ENTER(device);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, Cop = roundup(Co, 8);
     FOSVOS_REQUIRE(N < 65536, FOSVOS_E_ARG, "conv7x7s2_first_fwd: N=%d", N);
-    const ConvLaunch L = plan_conv2d((int64_t)N * Ho * Wo, Cop, 1);
     const int tiles_x = (int)cdiv(Wo, F7_TW), tiles_y = (int)cdiv(Ho, F7_TH);
-    const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)cdiv(Cop, L.cob), (unsigned)N);
     const int relu = (flags & FOSVOS_CONV_RELU) ? 1 : 0;
+    if (!(flags & FOSVOS_CONV_FP32_MATH) && Cop <= 64) {  // bf16 MFMA form
+        const uint4 *wimg = reinterpret_cast<const uint4 *>(w_packed + 147 * Cop + 64);
+        const dim3 g((unsigned)(tiles_x * tiles_y), 1, (unsigned)N);
+#define FOSVOS_GO(NFB)                                                                                                   \
+    hipLaunchKernelGGL(k_conv7x7s2_first_mfma<NFB>, g, dim3(256), 0, (hipStream_t)stream, frame, wimg, bias, y, H, W, Ho, Wo, \
+                       tiles_x, Cop, relu)
+        switch (f7_nc(Cop) / 16) {
+            case 1: FOSVOS_GO(1); break;
+            case 2: FOSVOS_GO(2); break;
+            case 3: FOSVOS_GO(3); break;
+            default: FOSVOS_GO(4); break;
+        }
+#undef FOSVOS_GO
+        FOSVOS_LAUNCH_CHECK();
+        return 0;
+    }
+    const ConvLaunch L = plan_conv2d((int64_t)N * Ho * Wo, Cop, 1);
+    const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)cdiv(Cop, L.cob), (unsigned)N);
     uint4 *yv = reinterpret_cast<uint4 *>(y);
 #define FOSVOS_GO(COB)                                                                                                \
     hipLaunchKernelGGL(k_conv7x7s2_first<COB>, grid, dim3(256), 0, (hipStream_t)stream, frame, w_packed, bias, yv, H, W, Ho, \
@@ -810,8 +918,9 @@ extern "C" int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *
     };
 
     int h = (H - 1) / 2 + 1, w = (W - 1) / 2 + 1;
-    if (int rc = fosvos_conv7x7s2_first_fwd(frame, net->first_w, net->first_b, first, N, H, W, net->first_co, FOSVOS_CONV_RELU,
-                                            device, stream))
+    if (int rc = fosvos_conv7x7s2_first_fwd(frame, net->first_w, net->first_b, first, N, H, W, net->first_co,
+                                            FOSVOS_CONV_RELU | (net->first_fp32_math ? FOSVOS_CONV_FP32_MATH : 0u), device,
+                                            stream))
         return rc;
     if (int rc = fosvos_maxpool3x3s2_fwd(first, slot[0], N, h, w, roundup(net->first_co, 8), device, stream)) return rc;
     h = (h - 1) / 2 + 1;

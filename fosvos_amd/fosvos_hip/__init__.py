@@ -66,7 +66,8 @@ class ResnetBlock(ctypes.Structure):
 
 class ResnetNet(ctypes.Structure):
     """fosvos_resnet_net (host struct; `blocks` points at a host array of ResnetBlock)."""
-    _fields_ = [("first_w", c_void_p), ("first_b", c_void_p), ("first_co", c_int), ("blocks_per_stage", c_int * 4),
+    _fields_ = [("first_w", c_void_p), ("first_b", c_void_p), ("first_co", c_int), ("first_fp32_math", c_int),
+                ("blocks_per_stage", c_int * 4),
                 ("blocks", POINTER(ResnetBlock)), ("side", Conv2dDesc * 4), ("filt", c_void_p * 4),
                 ("filt1", c_void_p * 4), ("stride", c_int * 4), ("dsn_w", c_void_p), ("dsn_b", c_void_p),
                 ("fuse_b", c_void_p)]

@@ -619,9 +619,13 @@ def pack_conv7x7_bn(w: torch.Tensor, bn: Optional[Sequence] = None):
     return packed, bias
 
 
+CONV_FP32_MATH = 4
+
+
 def conv7x7s2_first_fwd(frame: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, co: int,
-                        relu: bool = True) -> torch.Tensor:
-    """frame: fp32 NCHW [N,3,H,W] -> bf16 NHWC [N,(H-1)//2+1,(W-1)//2+1,ru8(co)]."""
+                        relu: bool = True, fp32_math: bool = False) -> torch.Tensor:
+    """frame: fp32 NCHW [N,3,H,W] -> bf16 NHWC [N,(H-1)//2+1,(W-1)//2+1,ru8(co)].  Default: bf16 MFMA (frame and
+    weights rounded to bf16, fp32 accumulate); fp32_math keeps both fp32 on the vector ALU."""
     _need(frame, _F32, "conv7x7s2_first_fwd frame")
     _need(packed, _F32, "conv7x7s2_first_fwd packed weights"); _need(bias, _F32, "conv7x7s2_first_fwd bias")
     n, c, h, w = frame.shape
@@ -635,7 +639,8 @@ def conv7x7s2_first_fwd(frame: torch.Tensor, packed: torch.Tensor, bias: torch.T
     dev, st = _ctx(frame)
     t0 = _pb()
     check(L.fosvos_conv7x7s2_first_fwd(frame.data_ptr(), packed.data_ptr(), bias.data_ptr(), y.data_ptr(), n, h, w, co,
-                                       CONV_RELU if relu else 0, dev, st), "conv7x7s2_first_fwd")
+                                       (CONV_RELU if relu else 0) | (CONV_FP32_MATH if fp32_math else 0), dev, st),
+          "conv7x7s2_first_fwd")
     _pe(t0, "conv7x7s2_first", 2.0 * n * ho * wo * 147 * co, 4 * frame.numel() + 2 * y.numel())
     return y
 

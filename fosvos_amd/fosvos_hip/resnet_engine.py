@@ -151,6 +151,7 @@ class ResnetPlan:
                 cb.down = b.down.desc()
         net = ResnetNet()
         net.first_w, net.first_b, net.first_co = self.first[0].data_ptr(), self.first[1].data_ptr(), self.c0
+        net.first_fp32_math = 0 if use_mfma() else 1
         for s in range(4):
             net.blocks_per_stage[s] = len(self.stages[s])
             net.side[s] = self.side[s].desc()
@@ -179,7 +180,7 @@ def forward_ops(net: nn.Module, plan: ResnetPlan, x: torch.Tensor) -> List[torch
     with torch.no_grad():
         plan.refresh(net)
         n, _c, h, w = x.shape
-        y = ops.conv7x7s2_first_fwd(x, plan.first[0], plan.first[1], plan.c0, relu=True)
+        y = ops.conv7x7s2_first_fwd(x, plan.first[0], plan.first[1], plan.c0, relu=True, fp32_math=not use_mfma())
         y = ops.maxpool3x3s2_fwd(y)
         sides = []
         for blocks, side in zip(plan.stages, plan.side):

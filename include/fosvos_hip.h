@@ -46,6 +46,7 @@ extern "C" {
 /* conv epilogue flags */
 #define FOSVOS_CONV_RELU 1u    /* y = max(y, 0)                                   */
 #define FOSVOS_CONV_OUT_F32 2u /* store fp32 NHWC instead of bf16 NHWC            */
+#define FOSVOS_CONV_FP32_MATH 4u /* fosvos_conv7x7s2_first_fwd only: fp32 frame and weights on the vector ALU */
 
 int fosvos_abi_version(void);
 const char *fosvos_last_error(void);
@@ -248,7 +249,9 @@ int fosvos_pack_conv2d_bn(const float *w_oihw, int Co, int Ci, int k /* 1 or 3 *
 int fosvos_conv2d_fwd(const uint16_t *x, const uint32_t *w_packed, const float *bias, const uint16_t *addend, void *y,
                       int N, int H, int W, int Ci, int Co, int k, int stride, unsigned flags, int device, void *stream);
 /* First layer: 7x7 stride 2 pad 3 on the fp32 NCHW frame (3 channels) + folded BatchNorm (+ ReLU) -> bf16 NHWC
- * [N,(H-1)/2+1,(W-1)/2+1,Cop].  Packed image: fp32 [49*3][Cop], fosvos_conv7x7_packed_elems floats.
+ * [N,(H-1)/2+1,(W-1)/2+1,Cop].  Packed image (fosvos_conv7x7_packed_elems floats): fp32 [49*3][Cop], then the same
+ * filter as bf16 MFMA fragments.  By default (Cop <= 64) the layer runs on the matrix cores with the frame rounded to
+ * bf16 like every other activation of the path; FOSVOS_CONV_FP32_MATH keeps frame and weights fp32 on the vector ALU.
  * replaces: layer_base conv1 + bn1 + relu (src/networks/osvos_resnet.py:92-94). */
 size_t fosvos_conv7x7_packed_elems(int out_ch);
 int fosvos_pack_conv7x7_bn(const float *w_oihw, int Co, const float *bn_weight, const float *bn_bias,
@@ -296,6 +299,7 @@ typedef struct fosvos_resnet_net {
     const float *first_w;       /* fosvos_pack_conv7x7_bn image */
     const float *first_b;
     int first_co;
+    int first_fp32_math;        /* != 0: FOSVOS_CONV_FP32_MATH for the first layer */
     int blocks_per_stage[4];
     const fosvos_resnet_block *blocks;
     fosvos_conv2d_desc side[4]; /* side_prep: 3x3 stride 1, Co = 16 */

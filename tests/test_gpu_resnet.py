@@ -145,26 +145,32 @@ def test_mfma_stride2_conv_matches_torch(ci, co, hw):
 
 
 def test_first_conv_and_pool_match_torch():
+    """Both forms of the 7x7 stride-2 layer: bf16 MFMA (the default; the reference gets the same bf16-rounded frame and
+    folded weights) and fp32 vector-ALU math (FOSVOS_CONV_FP32_MATH)."""
     from fosvos_hip import ops
     g = torch.Generator().manual_seed(3)
-    for co, (h, w) in ((16, (37, 53)), (64, (32, 48)), (21, (30, 31))):
+    for co, (h, w) in ((16, (37, 53)), (64, (32, 48)), (21, (30, 31)), (8, (64, 80)), (40, (19, 130))):
         x = 60.0 * torch.randn(2, 3, h, w, generator=g)
         wt = torch.randn(co, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5 / 60.0
         bn = _bn_params(co, g)
         packed, bias = ops.pack_conv7x7_bn(wt.to(DEV), tuple(t.to(DEV) for t in bn[:4]) + (bn[4],))
         s = bn[0] / torch.sqrt(bn[3] + bn[4])
-        ref = F.relu(F.conv2d(x, wt * s.view(-1, 1, 1, 1), bn[1] - bn[2] * s, stride=2, padding=3))
-        y = ops.conv7x7s2_first_fwd(x.to(DEV), packed, bias, co, relu=True)
-        p = ops.maxpool3x3s2_fwd(y)
-        torch.cuda.synchronize()
-        got = y.float().cpu()
-        assert torch.count_nonzero(got[..., co:]) == 0
-        got = got[..., :co].permute(0, 3, 1, 2)
-        assert got.shape == ref.shape
-        assert (got - ref).abs().max().item() <= 2.0 ** -8 * max(ref.abs().max().item(), 1.0) + 1e-5
-        # the pool works on what the conv stored: bit-exact against torch on the same bf16 values
-        want = F.max_pool2d(got, kernel_size=3, stride=2, padding=1)
-        assert torch.equal(p.float().cpu()[..., :co].permute(0, 3, 1, 2), want)
+        for fp32_math in (False, True):
+            if fp32_math:
+                ref = F.relu(F.conv2d(x, wt * s.view(-1, 1, 1, 1), bn[1] - bn[2] * s, stride=2, padding=3))
+            else:
+                ref = F.relu(F.conv2d(_bf(x), _bf(wt * s.view(-1, 1, 1, 1)), bn[1] - bn[2] * s, stride=2, padding=3))
+            y = ops.conv7x7s2_first_fwd(x.to(DEV), packed, bias, co, relu=True, fp32_math=fp32_math)
+            p = ops.maxpool3x3s2_fwd(y)
+            torch.cuda.synchronize()
+            got = y.float().cpu()
+            assert torch.count_nonzero(got[..., co:]) == 0
+            got = got[..., :co].permute(0, 3, 1, 2)
+            assert got.shape == ref.shape
+            assert (got - ref).abs().max().item() <= 2.0 ** -8 * max(ref.abs().max().item(), 1.0) + 1e-5, (co, fp32_math)
+            # the pool works on what the conv stored: bit-exact against torch on the same bf16 values
+            want = F.max_pool2d(got, kernel_size=3, stride=2, padding=1)
+            assert torch.equal(p.float().cpu()[..., :co].permute(0, 3, 1, 2), want)
 
 
 @pytest.mark.parametrize("h,w", [(64, 96), (70, 101), (33, 47)])

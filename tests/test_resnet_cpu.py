@@ -132,7 +132,9 @@ def test_host_side_size_queries():
     assert lib.fosvos_conv2d_packed_dwords(21, 13, 3) == 2 * 9 * 4 * 24 + 64          # both sides padded to 8
     assert lib.fosvos_conv2d_packed_dwords(32, 16, 1) == 2 * 1 * 4 * 32 + 64
     assert lib.fosvos_conv2d_packed_dwords(16, 16, 5) == 0
-    assert lib.fosvos_conv2d_bias_elems(21) == 64 + 64 and lib.fosvos_conv7x7_packed_elems(16) == 147 * 16 + 64
+    assert lib.fosvos_conv2d_bias_elems(21) == 64 + 64
+    assert lib.fosvos_conv7x7_packed_elems(16) == 147 * 16 + 64 + 6 * 4 * 16 * 8 // 2   # fp32 image, then bf16 MFMA fragments
+    assert lib.fosvos_conv7x7_packed_elems(24) == 147 * 24 + 64 + 6 * 4 * 32 * 8 // 2
 
     # arena arithmetic of the native loop on a ResNet-18 / exponent 2 shaped net (fake, never dereferenced pointers)
     fake = 0x1000
