@@ -24,30 +24,59 @@ def use_mfma() -> bool:
     return os.environ.get("FOSVOS_RESNET_MFMA", "1") != "0"
 
 
-class _Conv:
-    """One packed conv (+ folded BatchNorm).  3x3 stride-1 layers whose channel counts fit the MFMA implicit GEMM
-    (Ci % 32 == 0; Co % 64 == 0 or Co = 32) take that path (kind 1), everything else the vector-ALU direct conv (kind 0)."""
-    __slots__ = ("packed", "bias", "ci", "co", "k", "stride", "kind")
+def width(c: int) -> int:
+    """Channels a feature map is STORED with.  On the MFMA path every map is widened with zero channels to a count the
+    implicit GEMM takes on both sides (32, or a multiple of 64): a 16-, 8- or 59-channel layer then runs on the matrix
+    cores - padded weights, BatchNorm terms and biases are zero, so the extra channels hold exact zeros end to end and
+    the arithmetic on the real ones is unchanged.  Without MFMA: the next multiple of 8 (16-byte vectors)."""
+    if not use_mfma():
+        return (c + 7) // 8 * 8
+    return 32 if c <= 32 else (c + 63) // 64 * 64
 
-    def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], what: str, allow_mfma: bool = True) -> None:
+
+def _pad_to(t: Optional[torch.Tensor], n: int, value: float = 0.0) -> Optional[torch.Tensor]:
+    if t is None or t.shape[0] == n:
+        return t
+    out = torch.full((n,) + tuple(t.shape[1:]), value, dtype=t.dtype, device=t.device)
+    out[:t.shape[0]] = t
+    return out
+
+
+class _Conv:
+    """One packed conv (+ folded BatchNorm) between maps of physical widths ci_p -> co_p (see width()).  3x3 layers whose
+    physical channel counts fit the MFMA implicit GEMM (Ci % 32 == 0; Co % 64 == 0, Co = 32, or the 16-channel side_prep
+    form) take that path (kind 1), everything else the vector-ALU direct conv (kind 0)."""
+    __slots__ = ("packed", "bias", "ci", "co", "k", "stride", "kind", "ci_real", "co_real")
+
+    def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], what: str, ci_p: int, co_p: int,
+                 allow_mfma: bool = True) -> None:
         k = conv.kernel_size[0]
         if (conv.kernel_size not in ((1, 1), (3, 3)) or conv.stride not in ((1, 1), (2, 2)) or conv.dilation != (1, 1)
                 or conv.groups != 1 or conv.padding != (k // 2, k // 2)):
             raise NotImplementedError(f"{what}: {conv} - the HIP path has k in (1, 3), stride in (1, 2), padding k // 2")
         if bn is not None and (not bn.track_running_stats or bn.running_mean is None or not bn.affine):
             raise NotImplementedError(f"{what}: BatchNorm without affine running statistics cannot be folded")
-        self.ci, self.co, self.k, self.stride = conv.in_channels, conv.out_channels, k, conv.stride[0]
-        bnp = None if bn is None else (bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
-        cb = None if conv.bias is None else conv.bias.detach()
-        # (16 output channels is the side_prep shape: the MFMA path has a 16-wide tile with an fp32 store for it)
-        # stride 2 runs there too, with a subsampling store (fosvos_conv3x3_s2_fwd)
-        self.kind = int(allow_mfma and use_mfma() and k == 3 and self.ci % 32 == 0
-                        and (self.co % 64 == 0 or self.co == 32 or (self.co == 16 and self.stride == 1)))
+        self.ci_real, self.co_real = conv.in_channels, conv.out_channels
+        self.ci, self.co, self.k, self.stride = ci_p, co_p, k, conv.stride[0]
+        w = conv.weight.detach()
+        if (co_p, ci_p) != tuple(w.shape[:2]):
+            wp = torch.zeros((co_p, ci_p, k, k), dtype=w.dtype, device=w.device)
+            wp[:w.shape[0], :w.shape[1]] = w
+            w = wp
+        bnp = None
+        if bn is not None:  # padded channels: scale 0 (weight 0 over variance 1), shift 0
+            bnp = (_pad_to(bn.weight.detach(), co_p), _pad_to(bn.bias.detach(), co_p), _pad_to(bn.running_mean, co_p),
+                   _pad_to(bn.running_var, co_p, 1.0), bn.eps)
+        cb = None if conv.bias is None else _pad_to(conv.bias.detach(), co_p)
+        # (16 output channels is the side_prep shape: the MFMA path has a 16-wide tile with an fp32 store for it;
+        # stride 2 runs there too, with a subsampling store: fosvos_conv3x3_s2_fwd)
+        self.kind = int(allow_mfma and use_mfma() and k == 3 and ci_p % 32 == 0
+                        and (co_p % 64 == 0 or co_p == 32 or (co_p == 16 and self.stride == 1)))
         if self.kind:
-            folded, self.bias = ops.fold_conv_bn(conv.weight.detach(), cb, bnp)
+            folded, self.bias = ops.fold_conv_bn(w.contiguous(), cb, bnp)
             self.packed, _ = ops.pack_conv3x3_weights(folded, want_fwd=True, want_dgrad=False)
         else:
-            self.packed, self.bias = ops.pack_conv2d_bn(conv.weight.detach(), cb, bnp)
+            self.packed, self.bias = ops.pack_conv2d_bn(w.contiguous(), cb, bnp)
 
     def __call__(self, x: torch.Tensor, relu: bool, addend: Optional[torch.Tensor] = None,
                  out_f32: bool = False) -> torch.Tensor:
@@ -68,16 +97,31 @@ class _Conv:
 
 
 class _Block:
-    __slots__ = ("convs", "down")
+    __slots__ = ("convs", "down", "c_out")
 
-    def __init__(self, blk: nn.Module, what: str) -> None:
+    def __init__(self, blk: nn.Module, what: str, c_in: int) -> None:
         pairs = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
         if hasattr(blk, "conv3"):
             pairs.append((blk.conv3, blk.bn3))
-        self.convs = [_Conv(c, b, f"{what}.conv{i + 1}") for i, (c, b) in enumerate(pairs)]
+        self.convs = []
+        c = c_in
+        for i, (conv, bn) in enumerate(pairs):
+            if conv.in_channels != c:
+                raise RuntimeError(f"{what}.conv{i + 1} expects {conv.in_channels} input channels, its input has {c}")
+            if bn.num_features != conv.out_channels:
+                raise RuntimeError(f"{what}.bn{i + 1} has {bn.num_features} features for {conv.out_channels} channels")
+            self.convs.append(_Conv(conv, bn, f"{what}.conv{i + 1}", width(c), width(conv.out_channels)))
+            c = conv.out_channels
+        self.c_out = c
         self.down = None
         if blk.downsample is not None:
-            self.down = _Conv(blk.downsample[0], blk.downsample[1], f"{what}.downsample", allow_mfma=False)
+            dconv, dbn = blk.downsample[0], blk.downsample[1]
+            if dconv.in_channels != c_in or dconv.out_channels != c:
+                raise RuntimeError(f"{what}.downsample maps {dconv.in_channels} -> {dconv.out_channels} channels, the block "
+                                   f"{c_in} -> {c}")
+            self.down = _Conv(dconv, dbn, f"{what}.downsample", width(c_in), width(c), allow_mfma=False)
+        elif c != c_in:
+            raise RuntimeError(f"{what}: identity residual with {c_in} channels in and {c} out")
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         res = x if self.down is None else self.down(x, relu=False)
@@ -108,14 +152,30 @@ class ResnetPlan:
             raise NotImplementedError(f"layer_base conv {conv1}: the HIP path has the 7x7 stride-2 conv on 3-channel frames")
         if (pool.kernel_size, pool.stride, pool.padding, pool.ceil_mode) != (3, 2, 1, False):
             raise NotImplementedError(f"layer_base pool {pool}: the HIP path has MaxPool2d(3, 2, 1)")
-        self.c0 = conv1.out_channels
-        self.first = ops.pack_conv7x7_bn(conv1.weight.detach(),
-                                         (bn1.weight.detach(), bn1.bias.detach(), bn1.running_mean, bn1.running_var, bn1.eps))
-        self.stages: List[List[_Block]] = [[_Block(b, f"layer_stages.{i}.{j}") for j, b in enumerate(stage)]
-                                           for i, stage in enumerate(net.layer_stages)]
-        if len(self.stages) != 4:
+        c = conv1.out_channels
+        self.c0 = width(c)  # (the first layer writes the padded width too: zero filters, zero shift)
+        w1 = conv1.weight.detach()
+        if self.c0 != c:
+            w1p = torch.zeros((self.c0, 3, 7, 7), dtype=w1.dtype, device=w1.device)
+            w1p[:c] = w1
+            w1 = w1p
+        self.first = ops.pack_conv7x7_bn(w1.contiguous(),
+                                         (_pad_to(bn1.weight.detach(), self.c0), _pad_to(bn1.bias.detach(), self.c0),
+                                          _pad_to(bn1.running_mean, self.c0), _pad_to(bn1.running_var, self.c0, 1.0), bn1.eps))
+        if len(net.layer_stages) != 4 or len(net.side_prep) != 4:
             raise NotImplementedError("the side-output head takes exactly four stages")
-        self.side = [_Conv(m, None, f"side_prep.{i}") for i, m in enumerate(net.side_prep)]
+        self.stages: List[List[_Block]] = []
+        self.side: List[_Conv] = []
+        for i, stage in enumerate(net.layer_stages):
+            blocks = []
+            for j, b in enumerate(stage):
+                blocks.append(_Block(b, f"layer_stages.{i}.{j}", c))
+                c = blocks[-1].c_out
+            self.stages.append(blocks)
+            sp = net.side_prep[i]
+            if sp.in_channels != c:
+                raise RuntimeError(f"side_prep.{i} expects {sp.in_channels} input channels, the stage produces {c}")
+            self.side.append(_Conv(sp, None, f"side_prep.{i}", width(c), sp.out_channels))
         fuse_w = net.layer_fuse.weight.detach()
         if tuple(fuse_w.shape) != (1, 64, 1, 1) or any(s.co != 16 for s in self.side):
             raise NotImplementedError("the head kernel is built for 16-channel side maps and one output channel")
@@ -186,9 +246,6 @@ def forward_ops(net: nn.Module, plan: ResnetPlan, x: torch.Tensor) -> List[torch
         for blocks, side in zip(plan.stages, plan.side):
             for blk in blocks:
                 y = blk(y)
-            if blocks[-1].convs[-1].co != side.ci:
-                raise RuntimeError(f"side_prep expects {side.ci} input channels, the stage produces "
-                                   f"{blocks[-1].convs[-1].co}")
             sides.append(side(y, relu=False, out_f32=True))
         fused, outs = ops.deconv_head_fwd(sides, plan.strides, plan.filt, plan.filt1, plan.dsn_w, plan.dsn_b, plan.fuse_b,
                                           h, w, with_side_out=True)
