@@ -339,6 +339,31 @@ def test_bottleneck_trunk_runs_once_side_prep_fits():
     _check_net(net, sd, x)
 
 
+def test_full_size_frame_properties():
+    """BASELINE configs[4] size (1920x1080), where the oracle takes too long for a unit test: the native loop equals the
+    op-by-op loop bit for bit, repeated calls are deterministic, a batch row equals the same frame alone, and zero
+    weights in the head give the bias everywhere."""
+    from fosvos_hip import resnet_engine
+    from networks.osvos_resnet import OSVOS_RESNET
+    from oracle import osvos_resnet_ref as R
+    net = OSVOS_RESNET(pretrained=False, scale_down_exponent=2)
+    net.load_state_dict(R.make_state_dict(18, 2, seed=12))
+    net = net.to(DEV).eval()
+    x = (50.0 * torch.randn(2, 3, 1080, 1920, generator=torch.Generator().manual_seed(7))).to(DEV)
+    a = net(x)
+    b = resnet_engine.forward_ops(net, net._plan, x)
+    c = net(x[1:])
+    torch.cuda.synchronize()
+    assert all(t.shape == (2, 1, 1080, 1920) and torch.isfinite(t).all() for t in a)
+    for u, v, w in zip(a, b, c):
+        assert torch.equal(u, v) and torch.equal(u[1:], w)
+    with torch.no_grad():
+        net.layer_fuse.weight.zero_()
+        net.layer_fuse.bias.fill_(0.25)
+    fused = net(x)[-1]
+    assert torch.all(fused == 0.25)
+
+
 def test_loud_failures():
     from networks.osvos_resnet import OSVOS_RESNET
     net = OSVOS_RESNET(pretrained=False, scale_down_exponent=3).to(DEV)
