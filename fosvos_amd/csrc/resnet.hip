@@ -402,12 +402,14 @@ struct DeconvHeadArgs {
     int N, H, W, with_side_out;
 };
 
-// A workgroup owns 4 rows x 512 columns; a thread owns DH_PX pixels of one row, 64 columns apart: every stride
+// A workgroup owns 4 rows x 640 columns (three per row of a 1920-wide frame: 810 workgroups, which all fit the chip at
+// once - with 512 columns the 1080 workgroups needed a second round for the last 56: 51 vs 44 us; 960 columns: 47 us);
+// a thread owns DH_PX pixels of one row, 64 columns apart: every stride
 // divides 64, so they share the filter phase (ky, kx) at every scale and the 4 taps x 16 channels of filter live in
-// registers for all of them.  Per scale the side-map window under the tile (3 rows x (512 / f + 2) pixels, zeros
+// registers for all of them.  Per scale the side-map window under the tile (3 rows x (640 / f + 2) pixels, zeros
 // outside the map) is staged in LDS together with its score_dsn value d = dsn_b + dsn_w . side, computed once per
 // source pixel instead of once per output pixel and tap; the taps then read LDS (groups of f lanes share an address).
-constexpr int DH_PX = 8, DH_ROWS = 4, DH_COLS = 64 * DH_PX;
+constexpr int DH_PX = 10, DH_ROWS = 4, DH_COLS = 64 * DH_PX;
 constexpr int DH_NR = 3, DH_NC = DH_COLS / 4 + 2;  // window bound at the smallest stride (4)
 constexpr int DH_WIN = DH_NR * DH_NC;
 #define V4(v) f32x4{(v).x, (v).y, (v).z, (v).w}
