@@ -226,7 +226,8 @@ def _check_net(net, sd, x, frac=3e-2):
     return outs, ref
 
 
-@pytest.mark.parametrize("version,e,hw", [(18, 0, (64, 96)), (18, 2, (97, 130)), (18, 3, (120, 200)), (34, 2, (70, 101))])
+@pytest.mark.parametrize("version,e,hw", [(18, 0, (64, 96)), (18, 2, (97, 130)), (18, 3, (120, 200)), (34, 2, (70, 101)),
+                                          (18, 2, (16, 20)), (18, 1, (33, 17))])   # ... down to 1 x 1 stage-4 maps
 def test_network_matches_oracle(version, e, hw):
     from networks.osvos_resnet import OSVOS_RESNET
     from oracle import osvos_resnet_ref as R
