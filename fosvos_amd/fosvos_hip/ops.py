@@ -67,7 +67,7 @@ class OpProfiler:
 
     def __init__(self, detail: bool = False) -> None:
         self.records = []  # (name, flops, bytes, start_event, end_event)
-        self.detail = detail  # per-shape names for the generic conv (tools/resnet_infer_bench.py --detail)
+        self.detail = detail  # per-shape names for the generic conv (tests/bench_resnet_infer.py --detail)
 
     def summary(self):
         torch.cuda.synchronize()

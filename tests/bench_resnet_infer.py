@@ -1,7 +1,7 @@
 """OSVOS_RESNET inference at 1920x1080 on one MI355X (BASELINE.json configs[4]): ms/frame for a few
 (version, scale_down_exponent) pairs, a per-kernel breakdown from HIP events, and a parity spot check against the CPU
 oracle at a small size.  Not the headline metric - bench.py stays on the OSVOS_VGG fine-tune.
-usage: python tools/resnet_infer_bench.py [--json out.json] [--cpu]"""
+usage: python tests/bench_resnet_infer.py [--json out.json] [--cpu]"""
 import argparse
 import json
 import os

@@ -27,7 +27,7 @@ GRAD_COS = 0.99
 GRAD_REL_L2 = 0.15
 # Gradients vs the bf16-EMULATING oracle (same rounding points, fp32 accumulate).  Accumulation-order
 # differences flip individual bf16 roundings, and after a few layers those flips decorrelate the two runs
-# (tools/diag_layers.py: 36 % of conv5_3 activations differ by 1 ulp), so this is only moderately tighter
+# (tests/diag_layers.py: 36 % of conv5_3 activations differ by 1 ulp), so this is only moderately tighter
 # than the fp32 comparison; measured worst case cos 0.9981 / rel 6.2e-2.
 GRAD_COS_EMU = 0.995
 GRAD_REL_L2_EMU = 0.10
