@@ -11,9 +11,6 @@ Scope: eval-mode forward only.  BatchNorm uses its running stati
 front of it when the weights are packed (fosvos_hip/resnet_engine.py); a forward in training mode raises instead of
 falling back to anything.
 """
-from copy import deepcopy  # noqa: F401  (kept for parity with the reference module's namespace)
-
-import torch
 import torch.nn as nn
 
 from fosvos_hip import resnet_engine

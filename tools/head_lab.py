@@ -1,5 +1,5 @@
 """Time fosvos_deconv_head_fwd alone at 1080p, with and without the four side outputs.  usage: python tools/head_lab.py"""
-import os, sys, time, torch
+import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fosvos_amd"))
 from fosvos_hip import ops
