@@ -299,11 +299,24 @@ __global__ __launch_bounds__(256) void k_conv7x7s2_first_mfma(const float *__res
     const int oy0 = (tile / tiles_x) * F7_TH, ox0 = (tile % tiles_x) * F7_TW;
     const int64_t plane = (int64_t)H * W;
     const float *f0 = frame + (int64_t)n * 3 * plane;
-    for (int idx = tid; idx < 3 * F7_PH * F7_PW; idx += 256) {
-        const int ci = idx / (F7_PH * F7_PW), r = (idx / F7_PW) % F7_PH, c = idx % F7_PW;
-        const int iy = oy0 * 2 - 3 + r, ix = ox0 * 2 - 3 + c;
-        const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? f0[ci * plane + (int64_t)iy * W + ix] : 0.f;
-        sIn[r * F7_PITCH + c * 3 + ci] = f2bf(v);
+    // patch loads in batches of 6 from clamped addresses (zero padding applied as a select): rolled, with the load under
+    // a bounds branch, every element waited out its own trip to memory - 17 in a row per thread
+    constexpr int F7_N = 3 * F7_PH * F7_PW, F7_B = 6;
+    for (int base = tid; base < F7_N; base += 256 * F7_B) {
+        float v[F7_B];
+        int dst[F7_B];
+#pragma unroll
+        for (int u = 0; u < F7_B; ++u) {
+            const int idx = min(base + u * 256, F7_N - 1);
+            const int ci = idx / (F7_PH * F7_PW), r = (idx / F7_PW) % F7_PH, c = idx % F7_PW;
+            const int iy = oy0 * 2 - 3 + r, ix = ox0 * 2 - 3 + c;
+            const float t = f0[ci * plane + (int64_t)min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1)];
+            v[u] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? t : 0.f;
+            dst[u] = base + u * 256 < F7_N ? r * F7_PITCH + c * 3 + ci : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < F7_B; ++u)
+            if (dst[u] >= 0) sIn[dst[u]] = f2bf(v[u]);
     }
     // what only zero weights ever multiply must still be finite: the pad column of every row, the 8th filter row's patch
     // row and the few elements a last lane reads past it
@@ -354,6 +367,123 @@ __global__ __launch_bounds__(256) void k_conv7x7s2_first_mfma(const float *__res
             }
             *reinterpret_cast<uint2 *>(yp + ch0) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
         }
+    }
+}
+
+// First layer AND its 3x3 stride-2 max pool in one launch: the 540 x 960 conv map of a 1080p frame is never written (33-66
+// MB out and back in) - a workgroup owns 8 x 15 POOLED pixels, computes the 17 x 31 conv pixels under them (18 x 32 are
+// computed: 36 fragments of 16, 9 per wave) exactly as k_conv7x7s2_first_mfma does (same K order, so the same bits), keeps
+// them in LDS as bf16 after bias + ReLU, and pools from there.  Conv positions outside the map count as 0, which is
+// neutral under max because every window holds at least one real, ReLU'd (>= 0) value.
+constexpr int FP_PH = 8, FP_PW = 15, FP_CR = 2 * FP_PH + 2, FP_CC = 32, FP_ROWS = 2 * (FP_CR - 1) + 7;  // 18 x 32 conv, 41 rows
+
+template <int NFB>
+__global__ __launch_bounds__(256) void k_conv7x7s2_pool_first_mfma(const float *__restrict__ frame,
+                                                                   const uint4 *__restrict__ wimg,
+                                                                   const float *__restrict__ bias, uint16_t *__restrict__ yp,
+                                                                   int H, int W, int Ho, int Wo, int Hp, int Wp, int tiles_x,
+                                                                   int Cop) {
+    constexpr int NC = NFB * 16;
+    __shared__ __attribute__((aligned(16))) uint16_t sIn[(FP_ROWS + 1) * F7_PITCH + 8];
+    __shared__ __attribute__((aligned(16))) uint16_t sC[(FP_CR - 1) * FP_CC * NC];  // (row 17 is computed, never pooled)
+    const int tile = blockIdx.x, n = blockIdx.z, tid = threadIdx.x;
+    const int py0 = (tile / tiles_x) * FP_PH, px0 = (tile % tiles_x) * FP_PW;
+    const int cr0 = 2 * py0 - 1, cc0 = 2 * px0 - 1;  // conv position of local (0, 0)
+    const int64_t plane = (int64_t)H * W;
+    const float *f0 = frame + (int64_t)n * 3 * plane;
+    constexpr int FP_N = 3 * FP_ROWS * F7_PW, FP_B = 6;  // batched, unconditional loads: see k_conv7x7s2_first_mfma
+    for (int base = tid; base < FP_N; base += 256 * FP_B) {
+        float v[FP_B];
+        int dst[FP_B];
+#pragma unroll
+        for (int u = 0; u < FP_B; ++u) {
+            const int idx = min(base + u * 256, FP_N - 1);
+            const int ci = idx / (FP_ROWS * F7_PW), r = (idx / F7_PW) % FP_ROWS, c = idx % F7_PW;
+            const int iy = cr0 * 2 - 3 + r, ix = cc0 * 2 - 3 + c;
+            const float t = f0[ci * plane + (int64_t)min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1)];
+            v[u] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? t : 0.f;
+            dst[u] = base + u * 256 < FP_N ? r * F7_PITCH + c * 3 + ci : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < FP_B; ++u)
+            if (dst[u] >= 0) sIn[dst[u]] = f2bf(v[u]);
+    }
+    for (int idx = tid; idx < F7_PITCH + 8 + FP_ROWS + 1; idx += 256) {  // see k_conv7x7s2_first_mfma
+        if (idx < F7_PITCH + 8) sIn[FP_ROWS * F7_PITCH + idx] = 0;
+        else sIn[(idx - F7_PITCH - 8) * F7_PITCH + F7_PITCH - 1] = 0;
+    }
+    const int wave = tid >> 6, lane = tid & 63, l16 = lane & 15, kg = lane >> 4;
+    bf16x8 wf[6][NFB];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+        for (int nf = 0; nf < NFB; ++nf) wf[ks][nf] = __builtin_bit_cast(bf16x8, wimg[(ks * 4 + kg) * NC + nf * 16 + l16]);
+    float bv[NFB][4];
+#pragma unroll
+    for (int nf = 0; nf < NFB; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[nf][r] = bias[nf * 16 + kg * 4 + r];
+    __syncthreads();
+    // three fragments at a time: three independent MFMA chains hide each other's LDS reads (one at a time, a wave sat out
+    // every read's latency)
+#pragma unroll 1
+    for (int m0 = 0; m0 < 9; m0 += 3) {
+        f32x4 acc[3][NFB];
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int nf = 0; nf < NFB; ++nf) acc[u][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            const int k0 = ks * 32 + kg * 8, ky = k0 / 24, j0 = k0 % 24;
+            bf16x8 a[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int frag = wave * 9 + m0 + u, ly = frag >> 1, lx = (frag & 1) * 16 + l16;
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(sIn + (2 * ly + ky) * F7_PITCH + 6 * lx + j0);
+                a[u] = __builtin_bit_cast(bf16x8, make_uint4(p[0], p[1], p[2], p[3]));
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int nf = 0; nf < NFB; ++nf)
+                    acc[u][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nf], a[u], acc[u][nf], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int frag = wave * 9 + m0 + u, ly = frag >> 1, lx = (frag & 1) * 16 + l16;
+            const int cr = cr0 + ly, cc = cc0 + lx;
+            const bool real = cr >= 0 && cr < Ho && cc >= 0 && cc < Wo;
+            if (ly >= FP_CR - 1) continue;
+#pragma unroll
+            for (int nf = 0; nf < NFB; ++nf) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = real ? fmaxf(acc[u][nf][r] + bv[nf][r], 0.f) : 0.f;
+                *reinterpret_cast<uint2 *>(sC + (ly * FP_CC + lx) * NC + nf * 16 + kg * 4) =
+                    make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            }
+        }
+    }
+    __syncthreads();
+    const int cg = Cop >> 3;  // 8-channel groups that exist in the output
+    for (int idx = tid; idx < FP_PH * FP_PW * cg; idx += 256) {
+        const int g = idx % cg, q = idx / cg, pxl = q % FP_PW, pyl = q / FP_PW;
+        const int py = py0 + pyl, px = px0 + pxl;
+        if (py >= Hp || px >= Wp) continue;
+        float mx[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx[e] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                float v[8];
+                unpack8(*reinterpret_cast<const uint4 *>(sC + ((2 * pyl + dy) * FP_CC + 2 * pxl + dx) * NC + g * 8), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], v[e]);
+            }
+        *reinterpret_cast<uint4 *>(yp + (((int64_t)n * Hp + py) * Wp + px) * Cop + g * 8) = pack8(mx);
     }
 }
 
@@ -709,6 +839,32 @@ extern "C" int fosvos_conv7x7s2_first_fwd(const float *frame, const float *w_pac
     return 0;
 }
 
+extern "C" int fosvos_conv7x7s2_pool_first_fwd(const float *frame, const float *w_packed, const float *bias,
+                                               uint16_t *y_pooled, int N, int H, int W, int Co, int device, void *stream) {
+    FOSVOS_REQUIRE(frame && w_packed && bias && y_pooled, FOSVOS_E_ARG, "conv7x7s2_pool_first_fwd: null pointer");
+    FOSVOS_REQUIRE(N > 0 && N < 65536 && H > 0 && W > 0 && Co > 0, FOSVOS_E_ARG, "conv7x7s2_pool_first_fwd: N=%d H=%d W=%d Co=%d",
+                   N, H, W, Co);
+    const int Cop = roundup(Co, 8);
+    FOSVOS_REQUIRE(Cop <= 64, FOSVOS_E_SHAPE, "conv7x7s2_pool_first_fwd: at most 64 channels (got %d)", Co);
+    FOSVOS_ENTER(device);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, Hp = (Ho - 1) / 2 + 1, Wp = (Wo - 1) / 2 + 1;
+    const int tiles_x = (int)cdiv(Wp, FP_PW), tiles_y = (int)cdiv(Hp, FP_PH);
+    const uint4 *wimg = reinterpret_cast<const uint4 *>(w_packed + 147 * Cop + 64);
+    const dim3 g((unsigned)(tiles_x * tiles_y), 1, (unsigned)N);
+#define FOSVOS_GO(NFB)                                                                                                    \
+    hipLaunchKernelGGL(k_conv7x7s2_pool_first_mfma<NFB>, g, dim3(256), 0, (hipStream_t)stream, frame, wimg, bias, y_pooled, H, \
+                       W, Ho, Wo, Hp, Wp, tiles_x, Cop)
+    switch (f7_nc(Cop) / 16) {
+        case 1: FOSVOS_GO(1); break;
+        case 2: FOSVOS_GO(2); break;
+        case 3: FOSVOS_GO(3); break;
+        default: FOSVOS_GO(4); break;
+    }
+#undef FOSVOS_GO
+    FOSVOS_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int fosvos_maxpool3x3s2_fwd(const uint16_t *x, uint16_t *y, int N, int H, int W, int C, int device,
                                        void *stream) {
     FOSVOS_REQUIRE(x && y, FOSVOS_E_ARG, "maxpool3x3s2_fwd: null pointer");
@@ -920,11 +1076,19 @@ extern "C" int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *
     };
 
     int h = (H - 1) / 2 + 1, w = (W - 1) / 2 + 1;
-    if (int rc = fosvos_conv7x7s2_first_fwd(frame, net->first_w, net->first_b, first, N, H, W, net->first_co,
-                                            FOSVOS_CONV_RELU | (net->first_fp32_math ? FOSVOS_CONV_FP32_MATH : 0u), device,
-                                            stream))
-        return rc;
-    if (int rc = fosvos_maxpool3x3s2_fwd(first, slot[0], N, h, w, roundup(net->first_co, 8), device, stream)) return rc;
+    // (fused with the pool up to 32 channels: above, the conv tile in LDS leaves one workgroup per CU and the fused launch
+    // loses to the two kernels - 0.578 vs 0.55 ms per 1080p frame at 64 channels)
+    if (!net->first_fp32_math && !net->first_unfused && roundup(net->first_co, 8) <= 32) {
+        if (int rc = fosvos_conv7x7s2_pool_first_fwd(frame, net->first_w, net->first_b, slot[0], N, H, W, net->first_co, device,
+                                                     stream))
+            return rc;
+    } else {
+        if (int rc = fosvos_conv7x7s2_first_fwd(frame, net->first_w, net->first_b, first, N, H, W, net->first_co,
+                                                FOSVOS_CONV_RELU | (net->first_fp32_math ? FOSVOS_CONV_FP32_MATH : 0u), device,
+                                                stream))
+            return rc;
+        if (int rc = fosvos_maxpool3x3s2_fwd(first, slot[0], N, h, w, roundup(net->first_co, 8), device, stream)) return rc;
+    }
     h = (h - 1) / 2 + 1;
     w = (w - 1) / 2 + 1;
     int cur = 0, b = 0;

@@ -66,7 +66,7 @@ class ResnetBlock(ctypes.Structure):
 
 class ResnetNet(ctypes.Structure):
     """fosvos_resnet_net (host struct; `blocks` points at a host array of ResnetBlock)."""
-    _fields_ = [("first_w", c_void_p), ("first_b", c_void_p), ("first_co", c_int), ("first_fp32_math", c_int),
+    _fields_ = [("first_w", c_void_p), ("first_b", c_void_p), ("first_co", c_int), ("first_fp32_math", c_int), ("first_unfused", c_int),
                 ("blocks_per_stage", c_int * 4),
                 ("blocks", POINTER(ResnetBlock)), ("side", Conv2dDesc * 4), ("filt", c_void_p * 4),
                 ("filt1", c_void_p * 4), ("stride", c_int * 4), ("dsn_w", c_void_p), ("dsn_b", c_void_p),
@@ -135,6 +135,8 @@ SIGNATURES = {
                                        c_void_p, c_int, c_void_p]),
     "fosvos_conv7x7s2_first_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_uint,
                                            c_int, c_void_p]),
+    "fosvos_conv7x7s2_pool_first_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                                c_void_p]),
     "fosvos_maxpool3x3s2_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fosvos_deconv_head_fwd": (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                        POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p,

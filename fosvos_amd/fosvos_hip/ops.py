@@ -645,6 +645,28 @@ def conv7x7s2_first_fwd(frame: torch.Tensor, packed: torch.Tensor, bias: torch.T
     return y
 
 
+def conv7x7s2_pool_first_fwd(frame: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, co: int) -> torch.Tensor:
+    """layer_base in one launch (bf16 MFMA form): conv 7x7/2 + folded BatchNorm + ReLU + MaxPool2d(3, 2, 1);
+    frame fp32 NCHW [N,3,H,W] -> bf16 NHWC [N,Hp,Wp,ru8(co)]."""
+    _need(frame, _F32, "conv7x7s2_pool_first_fwd frame")
+    _need(packed, _F32, "conv7x7s2_pool_first_fwd packed weights"); _need(bias, _F32, "conv7x7s2_pool_first_fwd bias")
+    n, c, h, w = frame.shape
+    L = lib()
+    if c != 3:
+        raise ValueError("conv7x7s2_pool_first_fwd: 3-channel frames only")
+    if packed.numel() != L.fosvos_conv7x7_packed_elems(co) or bias.numel() != L.fosvos_conv2d_bias_elems(co):
+        raise ValueError("conv7x7s2_pool_first_fwd: packed image / bias size does not match co")
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    hp, wp = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
+    y = torch.empty((n, hp, wp, _ru(co, 8)), dtype=_BF16, device=frame.device)
+    dev, st = _ctx(frame)
+    t0 = _pb()
+    check(L.fosvos_conv7x7s2_pool_first_fwd(frame.data_ptr(), packed.data_ptr(), bias.data_ptr(), y.data_ptr(), n, h, w, co,
+                                            dev, st), "conv7x7s2_pool_first_fwd")
+    _pe(t0, "conv7x7s2_pool_first", 2.0 * n * ho * wo * 147 * co, 4 * frame.numel() + 2 * y.numel())
+    return y
+
+
 def maxpool3x3s2_fwd(x: torch.Tensor) -> torch.Tensor:
     _need(x, _BF16, "maxpool3x3s2_fwd")
     n, h, w, c = x.shape

@@ -140,7 +140,7 @@ class ResnetPlan:
 
     @staticmethod
     def _signature(net: nn.Module):
-        return (use_mfma(),) + tuple((t.data_ptr(), t._version) for t in list(net.parameters()) + list(net.buffers()))
+        return (use_mfma(), os.environ.get("FOSVOS_RESNET_FUSE_FIRST", "1")) + tuple((t.data_ptr(), t._version) for t in list(net.parameters()) + list(net.buffers()))
 
     def refresh(self, net: nn.Module) -> None:
         sig = self._signature(net)
@@ -212,6 +212,7 @@ class ResnetPlan:
         net = ResnetNet()
         net.first_w, net.first_b, net.first_co = self.first[0].data_ptr(), self.first[1].data_ptr(), self.c0
         net.first_fp32_math = 0 if use_mfma() else 1
+        net.first_unfused = int(os.environ.get("FOSVOS_RESNET_FUSE_FIRST", "1") == "0")
         for s in range(4):
             net.blocks_per_stage[s] = len(self.stages[s])
             net.side[s] = self.side[s].desc()
@@ -240,8 +241,11 @@ def forward_ops(net: nn.Module, plan: ResnetPlan, x: torch.Tensor) -> List[torch
     with torch.no_grad():
         plan.refresh(net)
         n, _c, h, w = x.shape
-        y = ops.conv7x7s2_first_fwd(x, plan.first[0], plan.first[1], plan.c0, relu=True, fp32_math=not use_mfma())
-        y = ops.maxpool3x3s2_fwd(y)
+        if use_mfma() and plan.c0 <= 32 and os.environ.get("FOSVOS_RESNET_FUSE_FIRST", "1") != "0":
+            y = ops.conv7x7s2_pool_first_fwd(x, plan.first[0], plan.first[1], plan.c0)   # conv + pool, one launch
+        else:
+            y = ops.conv7x7s2_first_fwd(x, plan.first[0], plan.first[1], plan.c0, relu=True, fp32_math=not use_mfma())
+            y = ops.maxpool3x3s2_fwd(y)
         sides = []
         for blocks, side in zip(plan.stages, plan.side):
             for blk in blocks:

@@ -259,6 +259,12 @@ int fosvos_pack_conv7x7_bn(const float *w_oihw, int Co, const float *bn_weight, 
                            int device, void *stream);
 int fosvos_conv7x7s2_first_fwd(const float *frame, const float *w_packed, const float *bias, uint16_t *y, int N, int H,
                                int W, int Co, unsigned flags, int device, void *stream);
+/* layer_base in ONE launch: conv 7x7/2 + folded BatchNorm + ReLU + MaxPool2d(3, 2, 1) -> bf16 NHWC
+ * [N,Hp,Wp,Cop], Hp = ((H-1)/2+1 - 1)/2 + 1; the conv map is never written.  MFMA form only (Cop <= 64); same bits as
+ * fosvos_conv7x7s2_first_fwd followed by fosvos_maxpool3x3s2_fwd.
+ * replaces: layer_base (src/networks/osvos_resnet.py:91-96). */
+int fosvos_conv7x7s2_pool_first_fwd(const float *frame, const float *w_packed, const float *bias, uint16_t *y_pooled, int N,
+                                    int H, int W, int Co, int device, void *stream);
 /* MaxPool2d(kernel 3, stride 2, padding 1) on bf16 NHWC, C % 8 == 0: [N,H,W,C] -> [N,(H-1)/2+1,(W-1)/2+1,C].
  * replaces: layer_base maxpool (src/networks/osvos_resnet.py:95). */
 int fosvos_maxpool3x3s2_fwd(const uint16_t *x, uint16_t *y, int N, int H, int W, int C, int device, void *stream);
@@ -300,6 +306,7 @@ typedef struct fosvos_resnet_net {
     const float *first_b;
     int first_co;
     int first_fp32_math;        /* != 0: FOSVOS_CONV_FP32_MATH for the first layer */
+    int first_unfused;          /* != 0: first layer and max pool as two launches (A/B runs) */
     int blocks_per_stage[4];
     const fosvos_resnet_block *blocks;
     fosvos_conv2d_desc side[4]; /* side_prep: 3x3 stride 1, Co = 16 */

@@ -173,6 +173,22 @@ def test_first_conv_and_pool_match_torch():
             assert torch.equal(p.float().cpu()[..., :co].permute(0, 3, 1, 2), want)
 
 
+def test_fused_first_conv_and_pool_equal_the_two_kernels():
+    """fosvos_conv7x7s2_pool_first_fwd (the conv map stays in LDS) against conv kernel + pool kernel: same bits."""
+    from fosvos_hip import ops
+    g = torch.Generator().manual_seed(13)
+    for co, (h, w) in ((16, (37, 53)), (32, (128, 250)), (64, (70, 64)), (21, (30, 31)), (8, (16, 20)), (40, (19, 130)),
+                       (32, (270, 483))):
+        x = 60.0 * torch.randn(2, 3, h, w, generator=g)
+        wt = torch.randn(co, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5 / 60.0
+        bn = _bn_params(co, g)
+        packed, bias = ops.pack_conv7x7_bn(wt.to(DEV), tuple(t.to(DEV) for t in bn[:4]) + (bn[4],))
+        want = ops.maxpool3x3s2_fwd(ops.conv7x7s2_first_fwd(x.to(DEV), packed, bias, co, relu=True))
+        got = ops.conv7x7s2_pool_first_fwd(x.to(DEV), packed, bias, co)
+        torch.cuda.synchronize()
+        assert got.shape == want.shape and torch.equal(got, want), (co, h, w)
+
+
 @pytest.mark.parametrize("h,w", [(64, 96), (70, 101), (33, 47)])
 def test_deconv_head_matches_torch(h, w):
     from fosvos_hip import ops
