@@ -287,6 +287,31 @@ __global__ __launch_bounds__(256) void k_conv7x7s2_first(const float *__restrict
 // values one output pixel needs from a patch row are contiguous and a lane's 8 consecutive k never leave a row; weights are
 // the row operand (a lane ends up with 4 consecutive channels of one pixel: an 8-byte store), all 6 x NFB weight fragments
 // stay in registers.  A workgroup owns 8 x 32 output pixels x all channels (Cop <= 64), a wave 2 rows of them.
+// Walks the [3 channels][rows][69 columns] input patch in steps of 256 elements without a division per element (the
+// decomposition of a flat index by constant divisions cost ~50 vector instructions per element: 1.2e7 per launch, more than
+// anything else in these kernels).  256 = 3 * 69 + 49.
+struct PatchWalk {
+    int ci, r, c;
+    __device__ __forceinline__ void start(int idx, int rows) {
+        ci = idx / (rows * F7_PW);
+        const int rem = idx - ci * rows * F7_PW;
+        r = rem / F7_PW;
+        c = rem - r * F7_PW;
+    }
+    __device__ __forceinline__ void step256(int rows) {
+        c += 49;
+        r += 3;
+        if (c >= F7_PW) {
+            c -= F7_PW;
+            r += 1;
+        }
+        if (r >= rows) {
+            r -= rows;
+            ci += 1;
+        }
+    }
+};
+
 constexpr int F7_PITCH = 208;  // bf16 per patch row: 69 pixels x 3 channels = 207, +1
 
 template <int NFB>
@@ -302,17 +327,19 @@ __global__ __launch_bounds__(256) void k_conv7x7s2_first_mfma(const float *__res
     // patch loads in batches of 6 from clamped addresses (zero padding applied as a select): rolled, with the load under
     // a bounds branch, every element waited out its own trip to memory - 17 in a row per thread
     constexpr int F7_N = 3 * F7_PH * F7_PW, F7_B = 6;
+    PatchWalk pw;
+    pw.start(tid, F7_PH);
     for (int base = tid; base < F7_N; base += 256 * F7_B) {
         float v[F7_B];
         int dst[F7_B];
 #pragma unroll
         for (int u = 0; u < F7_B; ++u) {
-            const int idx = min(base + u * 256, F7_N - 1);
-            const int ci = idx / (F7_PH * F7_PW), r = (idx / F7_PW) % F7_PH, c = idx % F7_PW;
+            const int ci = min(pw.ci, 2), r = pw.r, c = pw.c;
             const int iy = oy0 * 2 - 3 + r, ix = ox0 * 2 - 3 + c;
             const float t = f0[ci * plane + (int64_t)min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1)];
             v[u] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? t : 0.f;
-            dst[u] = base + u * 256 < F7_N ? r * F7_PITCH + c * 3 + ci : -1;
+            dst[u] = pw.ci < 3 ? r * F7_PITCH + c * 3 + ci : -1;
+            pw.step256(F7_PH);
         }
 #pragma unroll
         for (int u = 0; u < F7_B; ++u)
@@ -392,17 +419,19 @@ __global__ __launch_bounds__(256) void k_conv7x7s2_pool_first_mfma(const float *
     const int64_t plane = (int64_t)H * W;
     const float *f0 = frame + (int64_t)n * 3 * plane;
     constexpr int FP_N = 3 * FP_ROWS * F7_PW, FP_B = 6;  // batched, unconditional loads: see k_conv7x7s2_first_mfma
+    PatchWalk pw;
+    pw.start(tid, FP_ROWS);
     for (int base = tid; base < FP_N; base += 256 * FP_B) {
         float v[FP_B];
         int dst[FP_B];
 #pragma unroll
         for (int u = 0; u < FP_B; ++u) {
-            const int idx = min(base + u * 256, FP_N - 1);
-            const int ci = idx / (FP_ROWS * F7_PW), r = (idx / F7_PW) % FP_ROWS, c = idx % F7_PW;
+            const int ci = min(pw.ci, 2), r = pw.r, c = pw.c;
             const int iy = cr0 * 2 - 3 + r, ix = cc0 * 2 - 3 + c;
             const float t = f0[ci * plane + (int64_t)min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1)];
             v[u] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? t : 0.f;
-            dst[u] = base + u * 256 < FP_N ? r * F7_PITCH + c * 3 + ci : -1;
+            dst[u] = pw.ci < 3 ? r * F7_PITCH + c * 3 + ci : -1;
+            pw.step256(FP_ROWS);
         }
 #pragma unroll
         for (int u = 0; u < FP_B; ++u)
