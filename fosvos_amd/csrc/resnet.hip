@@ -314,6 +314,34 @@ struct PatchWalk {
 
 constexpr int F7_PITCH = 208;  // bf16 per patch row: 69 pixels x 3 channels = 207, +1
 
+// Stage a [3][ROWS][69] patch of the fp32 NCHW frame (top-left input pixel (y_base, x_base), zeros outside the frame) as
+// bf16 [row][69 x 3 interleaved] in LDS.  Frames whose width is a multiple of 4 take 16-byte loads (an aligned group of 4
+// columns is inside the frame or outside it as a whole): 19 groups per patch row instead of 69 scalar loads, and the
+// address arithmetic - most of these kernels' vector instructions - once per 4 elements.
+template <int ROWS>
+__device__ __forceinline__ bool stage_patch_vec4(const float *__restrict__ f0, int64_t plane, int y_base, int x_base, int H,
+                                                 int W, uint16_t *sIn, int tid) {
+    if ((W & 3) || (reinterpret_cast<uintptr_t>(f0) & 15)) return false;
+    const int xa = (x_base >= 0 ? x_base : x_base - 3) / 4 * 4;  // floor to a multiple of 4
+    constexpr int G = 19, ITEMS = 3 * ROWS * G;
+    for (int item = tid; item < ITEMS; item += 256) {
+        const int rp = item / G, g = item - rp * G;
+        const int ci = rp / ROWS, r = rp - ci * ROWS;
+        const int iy = y_base + r, x0 = xa + 4 * g;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < H && x0 >= 0 && x0 < W) v = *reinterpret_cast<const float4 *>(f0 + ci * plane + (int64_t)iy * W + x0);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        const int c0 = x0 - x_base;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0 + q;
+            if (c >= 0 && c < F7_PW) sIn[r * F7_PITCH + c * 3 + ci] = f2bf(e[q]);
+        }
+    }
+    return true;
+}
+
+
 template <int NFB>
 __global__ __launch_bounds__(256) void k_conv7x7s2_first_mfma(const float *__restrict__ frame, const uint4 *__restrict__ wimg,
                                                               const float *__restrict__ bias, uint16_t *__restrict__ y,
@@ -329,7 +357,8 @@ __global__ __launch_bounds__(256) void k_conv7x7s2_first_mfma(const float *__res
     constexpr int F7_N = 3 * F7_PH * F7_PW, F7_B = 6;
     PatchWalk pw;
     pw.start(tid, F7_PH);
-    for (int base = tid; base < F7_N; base += 256 * F7_B) {
+    const bool staged = stage_patch_vec4<F7_PH>(f0, plane, oy0 * 2 - 3, ox0 * 2 - 3, H, W, sIn, tid);
+    for (int base = tid; !staged && base < F7_N; base += 256 * F7_B) {
         float v[F7_B];
         int dst[F7_B];
 #pragma unroll
@@ -421,7 +450,8 @@ __global__ __launch_bounds__(256) void k_conv7x7s2_pool_first_mfma(const float *
     constexpr int FP_N = 3 * FP_ROWS * F7_PW, FP_B = 6;  // batched, unconditional loads: see k_conv7x7s2_first_mfma
     PatchWalk pw;
     pw.start(tid, FP_ROWS);
-    for (int base = tid; base < FP_N; base += 256 * FP_B) {
+    const bool staged = stage_patch_vec4<FP_ROWS>(f0, plane, cr0 * 2 - 3, cc0 * 2 - 3, H, W, sIn, tid);
+    for (int base = tid; !staged && base < FP_N; base += 256 * FP_B) {
         float v[FP_B];
         int dst[FP_B];
 #pragma unroll

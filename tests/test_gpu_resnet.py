@@ -149,7 +149,7 @@ def test_first_conv_and_pool_match_torch():
     folded weights) and fp32 vector-ALU math (FOSVOS_CONV_FP32_MATH)."""
     from fosvos_hip import ops
     g = torch.Generator().manual_seed(3)
-    for co, (h, w) in ((16, (37, 53)), (64, (32, 48)), (21, (30, 31)), (8, (64, 80)), (40, (19, 130))):
+    for co, (h, w) in ((16, (37, 53)), (64, (32, 48)), (21, (30, 31)), (8, (64, 80)), (40, (19, 130)), (32, (45, 132))):
         x = 60.0 * torch.randn(2, 3, h, w, generator=g)
         wt = torch.randn(co, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5 / 60.0
         bn = _bn_params(co, g)
@@ -178,7 +178,7 @@ def test_fused_first_conv_and_pool_equal_the_two_kernels():
     from fosvos_hip import ops
     g = torch.Generator().manual_seed(13)
     for co, (h, w) in ((16, (37, 53)), (32, (128, 250)), (64, (70, 64)), (21, (30, 31)), (8, (16, 20)), (40, (19, 130)),
-                       (32, (270, 483))):
+                       (32, (270, 483)), (32, (135, 244)), (16, (33, 4)), (32, (61, 1920))):   # widths % 4 == 0: 16-byte loads
         x = 60.0 * torch.randn(2, 3, h, w, generator=g)
         wt = torch.randn(co, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5 / 60.0
         bn = _bn_params(co, g)
