@@ -269,7 +269,10 @@ def forward(net: nn.Module, plan: ResnetPlan, x: torch.Tensor) -> List[torch.Ten
         raise RuntimeError(f"OSVOS_RESNET.forward: {msg}")
     if plan.arena is None or plan.arena.numel() < need or plan.arena.device != x.device:
         plan.arena = torch.empty(need, dtype=torch.uint8, device=x.device)
-    outs = [torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device) for _ in range(5)]
+    # net.compute_side_outputs = False (a caller that reads outputs[-1] only, like the reference's test loop,
+    # src/util/experiment_helper.py:49): the head skips the four side logit maps, empty placeholders take their place
+    with_side = bool(getattr(net, "compute_side_outputs", True))
+    outs = [torch.empty((n, 1, h, w) if with_side or i == 4 else (0,), dtype=torch.float32, device=x.device) for i in range(5)]
     dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
     aux = None
     # FOSVOS_RESNET_AUX=1 issues the side_prep / downsample convs on a second stream beside the trunk.  Off by default:
@@ -280,6 +283,7 @@ def forward(net: nn.Module, plan: ResnetPlan, x: torch.Tensor) -> List[torch.Ten
             plan.aux = torch.cuda.Stream(device=x.device)
         aux = plan.aux.cuda_stream
     check(L.fosvos_resnet_forward(ctypes.byref(plan.c_net), x.data_ptr(), n, h, w, plan.arena.data_ptr(),
-                                  plan.arena.numel(), outs[4].data_ptr(), ptr_array4([o.data_ptr() for o in outs[:4]]), dev,
+                                  plan.arena.numel(), outs[4].data_ptr(),
+                                  ptr_array4([o.data_ptr() if with_side else None for o in outs[:4]]), dev,
                                   torch.cuda.current_stream(dev).cuda_stream, aux), "resnet_forward")
     return outs

@@ -81,6 +81,9 @@ class OSVOS_RESNET(nn.Module):
         (self.side_prep, self.upscale_side_prep, self.score_dsn, self.upscale_score_dsn,
          self.layer_fuse) = self._make_osvos_layers(n_channels_side_inputs, n_channels_output)
         self._plan = resnet_engine.ResnetPlan()
+        # True (the reference's contract): forward returns the 4 side logit maps and the fused one.  A caller that reads
+        # outputs[-1] only may set it to False: the head then skips the side maps (empty placeholders are returned).
+        self.compute_side_outputs = True
         self._initialize_weights()
         if pretrained:
             self._load_from_pytorch(version)
@@ -94,6 +97,7 @@ class OSVOS_RESNET(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state.pop('_plan', None)
+        state['compute_side_outputs'] = True
         return state
 
     def __setstate__(self, state):

@@ -374,6 +374,10 @@ def test_full_size_frame_properties():
     assert all(t.shape == (2, 1, 1080, 1920) and torch.isfinite(t).all() for t in a)
     for u, v, w in zip(a, b, c):
         assert torch.equal(u, v) and torch.equal(u[1:], w)
+    net.compute_side_outputs = False                       # fused map only: same bits, empty placeholders for the rest
+    d = net(x)
+    assert torch.equal(d[-1], a[-1]) and all(t.numel() == 0 for t in d[:4])
+    net.compute_side_outputs = True
     with torch.no_grad():
         net.layer_fuse.weight.zero_()
         net.layer_fuse.bias.fill_(0.25)
