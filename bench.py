@@ -2,28 +2,41 @@
 """Headline benchmark: OSVOS-VGG one-shot online fine-tune throughput in 854x480 frames/s.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one iteration of the reference's online loop body (src/train_online.py:70-101) on one
-synthetic 1x3x480x854 frame already resident in HBM: forward (5 logit maps) -> class-balanced BCE on
-the fused map -> /avg_grad_every_n -> backward -> fused SGD step + zero_grad every 5th iteration.  It runs
-through the drop-in ``train_online._train`` with the drop-in ``OSVOS_VGG`` module, i.e. the shipped path.
+N > 1 works both ways: under ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (the ranks
+come from the environment) and as a plain ``python bench.py --gpus N``, which then starts N fresh child processes of
+itself, one per GPU, BEFORE it touches the GPU or imports torch (it never re-executes a process that did).
 
-N > 1 (one process per GPU, RCCL): data-parallel fine-tuning - every rank runs the same K steps on its
-own frames (weak scaling, per-GPU work fixed) and the flat fp32 gradient buffer (59.7 MB) is
-SUM-all-reduced over xGMI before each optimizer step.  ``--mode replicas`` instead runs N independent
-sequences with no collective (the reference's -sg/-sgs sharding).
+One "step" = one iteration of the reference's online loop body (src/train_online.py:70-101) on one synthetic
+1x3x480x854 frame already resident in HBM: forward -> class-balanced BCE on the fused map -> /avg_grad_every_n ->
+backward -> fused SGD step + zero_grad every 5th iteration.  It runs through the drop-in ``train_online._train`` with
+the drop-in ``OSVOS_VGG`` module, i.e. the shipped path (native layer loop, two-stream backward, deferred wgrad join).
 
-Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     : MFMA roofline of the conv3x3 implicit-GEMM kernels (fwd + dgrad + wgrad), per-launch
-                 durations measured with HIP events on the launch stream in a separate pass after
-                 the timed region; `by_kernel` lists every kernel family of the iteration
-  cpu_baseline : the CPU oracle (a port of the reference's arithmetic in plain torch fp32) timed on this
-                 box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+N > 1, one process per GPU over RCCL.  Two mappings of BASELINE.json configs[3] are timed in the same run:
+  dp        (``value``) every rank runs the same K steps on its own frames and the flat fp32 gradient buffer is
+            SUM-all-reduced (bucketed, overlapped with the backward pass) before each optimizer step: weak scaling,
+            5 local micro-batches per rank and step
+  replicas  (``replicas`` object) N independent sequences, no collective: the reference's own -sg/-sgs sharding
+            (src/train_online.py:178-189), the parity-preserving mapping
+The line carries ``backend``, ``ranks`` and ``distinct_devices``; ``n_gpus`` is the number of DISTINCT devices, and
+the nccl backend is refused when two ranks share one (a gloo rehearsal of two ranks on one GPU reads n_gpus 1).
+
+Extra objects on the one JSON line rank 0 prints:
+  roofline        MFMA roofline of the conv3x3 kernels (k_conv3x3_igemm forward + data gradient, k_wgrad3x3 weight
+                  gradient): per-launch durations from HIP events recorded by the library around every kernel ON ITS
+                  OWN LAUNCH STREAM (fosvos_profile_start/stop), over `--prof-steps` further steps of the same shipped
+                  execution right behind the timed region; `by_kernel` lists every kernel of the step under the name
+                  rocprofv3 prints (profiles/ holds the --kernel-trace --stats summary of this same command)
+  cpu_baseline    the CPU oracle (a port of the reference's arithmetic in plain torch fp32) on this box's host cores:
+                  2 warm-up + 10 timed iterations of the same workload, rank 0, N = 1 only
+  infer           the reference's own timing protocol for its only published number (src/util/experiment_helper.py:
+                  29-53,77-80: net.forward between device syncs, 10 passes, first frame of each pass dropped)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,8 +47,7 @@ sys.path.insert(0, os.path.join(ROOT, "fosvos_amd"))
 H, W = 480, 854
 AVG_GRAD_EVERY_N = 5
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
-HBM_PEAK_GBS = 8000.0
-CONV_TRAIN_GFLOP_PER_FRAME = 773.27  # fwd + dgrad + wgrad of the 3x3 convs, no dgrad into the image
+CONV_KERNEL_PREFIXES = ("k_conv3x3_igemm", "k_wgrad")  # the MFMA family the roofline object is about
 
 
 def parse():
@@ -43,16 +55,36 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", choices=["dp", "replicas"], default="dp")
+    ap.add_argument("--mode", choices=["both", "dp", "replicas"], default="both",
+                    help="N > 1: which mapping(s) to time; `value` is dp unless only replicas is asked for")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-infer", action="store_true")
+    ap.add_argument("--prof-steps", type=int, default=20)
+    ap.add_argument("--cpu-iters", type=int, default=10)
     return ap.parse_args()
 
 
+def launch_children(args) -> int:
+    """`python bench.py --gpus N` outside torchrun: N fresh children, one per GPU.  This parent has not imported torch
+    and makes no GPU call; it only waits and forwards exit codes."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FOSVOS_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def cpu_baseline(iters: int):
-    """The oracle's online loop on the host cores: 1 warm-up + `iters` timed fwd+bwd iterations of the same
-    480x854 workload (SGD step every 5th iteration included when it falls inside the sample)."""
+    """The oracle's online loop on the host cores: 2 warm-up + `iters` timed fwd+bwd iterations of the same 480x854
+    workload, the SGD step of every 5th iteration inside the sample."""
     import torch
     from oracle import osvos_ref as O
     # the GPU box gives one GPU's job a 16-core share of the host; more threads than that only oversubscribe
@@ -74,97 +106,131 @@ def cpu_baseline(iters: int):
             opt.step()
             opt.zero_grad()
 
-    one(-1)  # warm-up (oneDNN primitive creation)
+    for i in range(2):
+        one(-2 + i)  # warm-up (oneDNN primitive creation); no optimizer step falls in here
+    opt.zero_grad()
     t0 = time.perf_counter()
     for i in range(iters):
         one(i)
     dt = time.perf_counter() - t0
     return {"value": iters / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 warm-up + {iters} timed fwd+loss+bwd iterations at 1x3x{H}x{W} fp32 (oracle/osvos_ref.py, "
-                      f"torch {torch.__version__} CPU), {dt / iters * 1000:.0f} ms/iter"}
+            "sample": f"2 warm-up + {iters} timed fwd+loss+bwd iterations (SGD step every {AVG_GRAD_EVERY_N}th) at "
+                      f"1x3x{H}x{W} fp32 (oracle/osvos_ref.py, torch {torch.__version__} CPU), {dt / iters * 1000:.0f} ms/iter"}
 
 
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        sys.exit(launch_children(args))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or run "
+                         f"`python bench.py --gpus {args.gpus}` outside torchrun and let it start its own ranks")
+
     import torch
     import torch.distributed as dist
     import fosvos_amd  # noqa: F401
     import parallel
     import train_online
     from dataloaders.synthetic import make_frame
-    from fosvos_hip import ops
+    from fosvos_hip import LaunchProfile
     from networks.osvos_vgg import OSVOS_VGG
     from util.network_provider import VGGOnlineProvider
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks "
-                             f"(WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # one process per GPU; FOSVOS_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals on a 1-GPU box
-    backend = os.environ.get("FOSVOS_DIST_BACKEND", "nccl")
-    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU over RCCL; FOSVOS_DIST_BACKEND=gloo lets several ranks share a GPU for rehearsals on a 1-GPU box
+    backend = os.environ.get("FOSVOS_DIST_BACKEND", "nccl") if world > 1 else "none"
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible - RCCL needs one device per "
+                         f"rank (FOSVOS_DIST_BACKEND=gloo rehearses several ranks on one GPU)")
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    distinct = 1
     if world > 1:
-        if backend == "nccl":
-            parallel.init_distributed("nccl")
-        else:
-            dist.init_process_group(backend=backend)
+        dist.init_process_group(backend=backend)
+        props = torch.cuda.get_device_properties(dev_index)
+        ident = (socket.gethostname(), str(getattr(props, "uuid", dev_index)), dev_index)
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        distinct = len(set(idents))
+        if backend == "nccl" and distinct != world:
+            raise SystemExit(f"{world} RCCL ranks on {distinct} distinct device(s): refusing to run")
 
     # ---- model: seeded random-init weights of the real architecture (no checkpoints offline)
-    torch.manual_seed(1234)
-    net = OSVOS_VGG(pretrained=0)
-    # variance-preserving init so activations/gradients are O(1)-O(100) like a trained net (the reference's
-    # N(0,1e-3) init collapses every activation to ~0 after 13 layers)
-    with torch.no_grad():
-        for name, p in net.named_parameters():
-            if name.startswith("upscale"):
-                continue
-            if p.dim() == 4:
-                fan_in = p.shape[1] * p.shape[2] * p.shape[3]
-                p.normal_(0, (2.0 / fan_in) ** 0.5 if name.startswith("stages") else (1.0 / fan_in) ** 0.5)
-            else:
-                p.normal_(0, 0.1)
-    net = net.to(dev)
-    prov = VGGOnlineProvider.__new__(VGGOnlineProvider)
-    prov.network = net
-    prov.name = "vgg16"
-    opt = prov.get_optimizer()
+    def make_provider():
+        torch.manual_seed(1234)
+        net = OSVOS_VGG(pretrained=0)
+        # variance-preserving init so activations/gradients are O(1)-O(100) like a trained net (the reference's
+        # N(0,1e-3) init collapses every activation to ~0 after 13 layers)
+        with torch.no_grad():
+            for name, p in net.named_parameters():
+                if name.startswith("upscale"):
+                    continue
+                if p.dim() == 4:
+                    fan_in = p.shape[1] * p.shape[2] * p.shape[3]
+                    p.normal_(0, (2.0 / fan_in) ** 0.5 if name.startswith("stages") else (1.0 / fan_in) ** 0.5)
+                else:
+                    p.normal_(0, 0.1)
+        prov = VGGOnlineProvider.__new__(VGGOnlineProvider)
+        prov.network = net.to(dev)
+        prov.name = "vgg16"
+        return prov, prov.get_optimizer()
+
     img, gt = make_frame(H, W, seed=1234, index=rank)
     batch = [{"image": img.unsqueeze(0).to(dev), "gt": gt.unsqueeze(0).to(dev)}]  # resident in HBM
-    train_online.data_parallel = world > 1 and args.mode == "dp"
-    accum = AVG_GRAD_EVERY_N * (world if train_online.data_parallel else 1)  # each rank accumulates 5 micro-batches
-
-    def run(n_steps):
-        return train_online._train(prov, batch, opt, _NullWriter(), "bench", 0, n_steps, accum, 10 ** 9)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(mode):
+        """W warm-up + exactly K timed steps of `mode`, barrier + device sync on both sides, MAX over ranks."""
+        prov, opt = make_provider()
+        train_online.data_parallel = world > 1 and mode == "dp"
+        accum = AVG_GRAD_EVERY_N * (world if train_online.data_parallel else 1)  # 5 local micro-batches per rank
 
-    frames = args.steps * world
+        def run(n_steps):
+            return train_online._train(prov, batch, opt, _NullWriter(), "bench", 0, n_steps, accum, 10 ** 9)
+
+        run(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        train_online.data_parallel = False
+        return elapsed, prov, opt, run
+
+    modes = ["single"] if world == 1 else (["dp", "replicas"] if args.mode == "both" else [args.mode])
+    results = {}
+    for m in modes:
+        results[m] = timed(m)
+    head = modes[0]
+    elapsed, prov, opt, run = results[head]
+
+    def parallelism(m):
+        if m == "single":
+            return "single GPU"
+        if m == "dp":
+            return (f"dp{world}: 5 local micro-batches per rank and step, bucketed fp32 gradient all-reduce (59.7 MB per "
+                    f"optimizer step, {backend}) overlapped with the backward pass")
+        return f"{world} independent replicas (one sequence per rank, src/train_online.py:178-189), no collective"
+
     out = {
         "metric": "online fine-tune frames/sec (854x480)",
-        "value": frames / elapsed,
+        "value": args.steps * world / elapsed,
         "unit": "frames/s",
-        "n_gpus": world,
+        "n_gpus": distinct,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1000.0,
@@ -173,45 +239,41 @@ def main():
         "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic",
+        "backend": {"nccl": "nccl (RCCL)"}.get(backend, backend),
+        "ranks": world,
+        "distinct_devices": distinct,
         "config": {
             "workload": "OSVOS_VGG train_online one-shot fine-tune: 1x3x480x854 frame per step, fwd + class-balanced "
                         "BCE + bwd, fused SGD step every 5 steps (BASELINE.json configs[1])",
             "frame": [H, W], "batch": 1, "avg_grad_every_n": AVG_GRAD_EVERY_N,
             "activations": "bf16 NHWC, fp32 accumulate, fp32 master weights",
-            "parallelism": (f"dp{world}: flat fp32 gradient all-reduce (59.7 MB, RCCL) per optimizer step"
-                            if train_online.data_parallel else
-                            (f"{world} independent replicas, no collective" if world > 1 else "single GPU")),
+            "parallelism": parallelism(head),
         },
     }
+    for m in modes[1:]:
+        e = results[m][0]
+        out[m] = {"value": args.steps * world / e, "unit": "frames/s", "ms_per_step": e / args.steps * 1000.0,
+                  "parallelism": parallelism(m)}
 
     if rank == 0 and not args.no_roofline:
-        # rank-0-only pass: it must not issue collectives (the other ranks are already at the final barrier)
-        dp_was = train_online.data_parallel
+        # rank-0-only pass, so no collective: the single-process loop (what every replica runs; the dp loop differs only by
+        # the all-reduce).  Same shipped execution as the timed region - native layer loop, two streams, deferred join -
+        # with the library's event pair around every launch on its own stream.
         train_online.data_parallel = False
-        from fosvos_hip import engine
-        native_was = engine.USE_NATIVE_LOOP
-        engine.USE_NATIVE_LOOP = False  # same kernels, issued op by op from Python so that each op can be bracketed
-        prof = ops.OpProfiler()
-        ops.set_profiler(prof)
-        n_prof = 5
-        train_online._train(prov, batch, opt, _NullWriter(), "bench", 0, n_prof, AVG_GRAD_EVERY_N, 10 ** 9)
-        ops.set_profiler(None)
-        engine.USE_NATIVE_LOOP = native_was
-        train_online.data_parallel = dp_was
-        agg = prof.summary()
+        n_prof = max(AVG_GRAD_EVERY_N, args.prof_steps // AVG_GRAD_EVERY_N * AVG_GRAD_EVERY_N)
+        with LaunchProfile(dev_index) as prof:
+            train_online._train(prov, batch, opt, _NullWriter(), "bench", 0, n_prof, AVG_GRAD_EVERY_N, 10 ** 9)
         by_kernel = {}
-        for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
-            per_iter_ms = a["ms"] / n_prof
+        for name, a in sorted(prof.records.items(), key=lambda kv: -kv[1]["ms"]):
             by_kernel[name] = {
-                "launches_per_step": a["calls"] / n_prof,
-                "ms_per_step": round(per_iter_ms, 4),
-                "avg_us_per_launch": round(a["ms"] / a["calls"] * 1000.0, 2),
+                "launches_per_step": a["launches"] / n_prof,
+                "ms_per_step": round(a["ms"] / n_prof, 4),
+                "avg_us_per_launch": round(a["ms"] / a["launches"] * 1000.0, 2),
                 "tflops": round(a["flops"] / a["ms"] / 1e9, 2) if a["flops"] else None,
-                "gbs": round(a["bytes"] / a["ms"] / 1e6, 1),
             }
-        conv = [agg[k] for k in ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad") if k in agg]
+        conv = [a for k, a in prof.records.items() if k.startswith(CONV_KERNEL_PREFIXES)]
         conv_ms = sum(a["ms"] for a in conv) / n_prof
-        conv_calls = sum(a["calls"] for a in conv) / n_prof
+        conv_calls = sum(a["launches"] for a in conv) / n_prof
         conv_flop = sum(a["flops"] for a in conv) / n_prof
         achieved = conv_flop / (conv_ms * 1e-3) / 1e12
         # HBM bytes per launch of the same kernel family from the committed PMC passes (rocprofv3 cannot run inside
@@ -229,19 +291,32 @@ def main():
             traffic_note = f"could not read PMC summary: {e}"
         out["roofline"] = {
             "bound": "mfma",
-            "kernel": "conv3x3 implicit-GEMM family (k_conv3x3_igemm fwd+dgrad, k_wgrad), bf16 MFMA 16x16x32",
+            "kernel": "conv3x3 MFMA family: k_conv3x3_igemm (forward + data gradient) and k_wgrad* (weight gradient), bf16",
             "achieved": achieved,
             "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
             "traffic": traffic,
             "traffic_note": traffic_note,
+            "measured": f"HIP event pairs on each kernel's launch stream, {n_prof} steps of the shipped two-stream execution "
+                        f"right behind the timed region (kernels of the two streams overlap, as under rocprofv3)",
             "launches_per_step": conv_calls,
             "algorithmic_gflop_per_step": conv_flop / 1e9,
             "avg_launch_us": conv_ms / conv_calls * 1000.0,
-            "device_ms_per_step_all_kernels": sum(a["ms"] for a in agg.values()) / n_prof,
+            "device_ms_per_step_all_kernels": sum(a["ms"] for a in prof.records.values()) / n_prof,
             "by_kernel": by_kernel,
         }
+    if rank == 0 and not args.no_infer:
+        # f1: the reference's eval_speeds protocol on 480x854 frames, all five logit maps computed
+        from util import experiment_helper, io_helper
+        loader = io_helper.get_data_loader_test(None, 1, "bench", synthetic=(H, W), n_frames=6)
+        sec = experiment_helper.test(prov, loader, os.path.join(ROOT, "gpurun_out", "bench_infer"), False, True, seq_name="bench")
+        ev = experiment_helper.last_eval
+        out["infer"] = {"infer_ms_per_frame": sec * 1000.0, "frames_per_s": 1.0 / sec, "frame": [H, W], "outputs": 5,
+                        "protocol": f"net.forward between device syncs, {ev['n_runs']} passes x {len(loader)} frames, first "
+                                    f"frame of each pass dropped ({len(ev['times'])} samples; host-to-device copy of the "
+                                    f"frame outside the bracket), src/util/experiment_helper.py:29-53",
+                        "reference_published_s_per_frame": 0.08083}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_iters)
     if world > 1:

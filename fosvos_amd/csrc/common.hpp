@@ -38,7 +38,21 @@ inline int fail(int code, const char *fmt, ...) {
 
 // Select the device for this call (backward runs on an autograd thread with its own current device).
 #define FOSVOS_ENTER(device) FOSVOS_HIP_CHECK(hipSetDevice(device))
-#define FOSVOS_LAUNCH_CHECK() FOSVOS_HIP_CHECK(hipGetLastError())
+// Launch profiler (util.hip; fosvos_profile_start / _stop): when on, every kernel launch of the library is bracketed
+// by a pair of timing events ON THE STREAM IT IS LAUNCHED ON.  FOSVOS_PROF(name, stream, flops) goes in front of a
+// launch, FOSVOS_LAUNCH_CHECK() behind it closes the bracket.  Off (the default): one predictable branch per launch.
+extern bool g_prof_on;
+void prof_begin(const char *name, hipStream_t st, double flops);
+void prof_end();
+#define FOSVOS_PROF(name, st, flops)                                        \
+    do {                                                                    \
+        if (::fosvos::g_prof_on) ::fosvos::prof_begin(name, (hipStream_t)(st), flops); \
+    } while (0)
+#define FOSVOS_LAUNCH_CHECK()                            \
+    do {                                                 \
+        if (::fosvos::g_prof_on) ::fosvos::prof_end();   \
+        FOSVOS_HIP_CHECK(hipGetLastError());             \
+    } while (0)
 
 // Weight-gradient reduction queue (conv_wgrad.hip): the MFMA kernel of a layer writes per-split slabs; the fold /
 // final passes that turn them into dw/db can run right away (reduce == nullptr) or be queued here and run for all

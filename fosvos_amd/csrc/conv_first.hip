@@ -126,6 +126,7 @@ extern "C" int fosvos_conv3x3_first_fwd(const float *frame, const float *w, cons
                    N, H, W);
     FOSVOS_ENTER(device);
     dim3 grid((unsigned)cdiv(W, TW), (unsigned)cdiv(H, ROWS), (unsigned)N);
+    FOSVOS_PROF("k_first_fwd", stream, 2.0 * N * H * W * 27 * Co);
     hipLaunchKernelGGL(k_first_fwd, grid, dim3(256), 0, (hipStream_t)stream, frame, w, bias, y, H, W);
     FOSVOS_LAUNCH_CHECK();
     return FOSVOS_OK;

@@ -606,7 +606,7 @@ ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
 }
 
 template <class T, bool OUT_F32>
-int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st) {
+int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st, int in_ch) {
     ConvArgs a = a0;
     a.tiles_x = (int)cdiv(a.W, T::TW);
     a.tiles_y = (int)cdiv(a.H, T::TH);
@@ -617,6 +617,12 @@ int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st) {
 #endif
     const int64_t tiles = (int64_t)a.tiles_x * a.tiles_y * a.N;
     FOSVOS_REQUIRE(tiles <= 0x7fffffff && a.Cout % T::BN == 0, FOSVOS_E_SHAPE, "conv3x3: tile grid");
+    if (g_prof_on) {  // the name rocprofv3 prints for this instantiation
+        static char name[80];
+        snprintf(name, sizeof(name), "k_conv3x3_igemm<Tile<%d, %d, %d, %d, %d>, %s>", T::TH, T::TW, T::BN, T::WM, T::WN,
+                 OUT_F32 ? "true" : "false");
+        prof_begin(name, st, 2.0 * a.N * a.H * a.W * 9.0 * in_ch * a.Cout);
+    }
     hipLaunchKernelGGL((k_conv3x3_igemm<T, OUT_F32>),
                        dim3((unsigned)tiles, (unsigned)(a.Cout / T::BN), (unsigned)plan.k_splits), dim3(256),
                        T::LDS_BYTES, st, a);
@@ -626,6 +632,7 @@ int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st) {
                                                        : (int64_t)a.N * a.H * a.W * (a.Cout / 8);
         int64_t g = cdiv(total8, 256);
         if (g > 4096) g = 4096;
+        FOSVOS_PROF("k_splitk_epilogue", st, 0.0);
         hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)g), dim3(256), 0, st, a, total8);
         FOSVOS_LAUNCH_CHECK();
     }
@@ -656,13 +663,13 @@ int dispatch(ConvArgs a, int in_ch, void *workspace, size_t workspace_bytes, hip
         a.partial = reinterpret_cast<float *>(workspace);
     }
     switch (plan.tile) {
-        case kBig: return launch<TileBig, false>(a, plan, st);
-        case kMid: return launch<TileMid, false>(a, plan, st);
-        case kSmall: return launch<TileSmall, false>(a, plan, st);
-        case kSide: return f32 ? launch<TileSide, true>(a, plan, st) : launch<TileSide, false>(a, plan, st);
-        case kSideS: return f32 ? launch<TileSideS, true>(a, plan, st) : launch<TileSideS, false>(a, plan, st);
-        case kHalf: return launch<TileHalf, false>(a, plan, st);
-        case kHalfS: return launch<TileHalfS, false>(a, plan, st);
+        case kBig: return launch<TileBig, false>(a, plan, st, in_ch);
+        case kMid: return launch<TileMid, false>(a, plan, st, in_ch);
+        case kSmall: return launch<TileSmall, false>(a, plan, st, in_ch);
+        case kSide: return f32 ? launch<TileSide, true>(a, plan, st, in_ch) : launch<TileSide, false>(a, plan, st, in_ch);
+        case kSideS: return f32 ? launch<TileSideS, true>(a, plan, st, in_ch) : launch<TileSideS, false>(a, plan, st, in_ch);
+        case kHalf: return launch<TileHalf, false>(a, plan, st, in_ch);
+        case kHalfS: return launch<TileHalfS, false>(a, plan, st, in_ch);
     }
     return fail(FOSVOS_E_ARG, "conv3x3: bad plan");
 }

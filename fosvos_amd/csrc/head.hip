@@ -309,6 +309,7 @@ struct HeadBwdLaunch {
             FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         dim3 grid((unsigned)cdiv(ws, HeadTile<S>::TJ), (unsigned)cdiv(hs, HeadTile<S>::TI), (unsigned)N);
+        FOSVOS_PROF("k_head_bwd_scale", st, 0.0);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, side, filt, filt1, fw16, dw16, d_fused, d_so, d_side, slabs, hs,
                            ws, top, left, H, W);
         FOSVOS_LAUNCH_CHECK();
@@ -397,6 +398,7 @@ extern "C" int fosvos_head_fwd(const float *const side[4], const int hs[4], cons
     FOSVOS_ENTER(device);
     FOSVOS_REQUIRE(N <= 65535, FOSVOS_E_SHAPE, "head_fwd: batch %d", N);
     const dim3 grid((unsigned)cdiv(W, HF_TX), (unsigned)cdiv(H, HF_TY), (unsigned)N);
+    FOSVOS_PROF("k_head_fwd", stream, 0.0);
     if (with_so)
         hipLaunchKernelGGL(k_head_fwd<true>, grid, dim3(256), 0, (hipStream_t)stream, p, g, dsn_w, dsn_b, fuse_w, fuse_b,
                            fused, side_out[0], side_out[1], side_out[2], side_out[3], H, W);
@@ -523,10 +525,12 @@ int fosvos::head_bwd_finish(const HeadBwdArgs &a, void *stream) {
     fa.accumulate = a.accumulate;
     if (a.d_fused) {
         fa.n_bias = kBiasBlocks;
+        FOSVOS_PROF("k_sum_partials", st, 0.0);
         hipLaunchKernelGGL(k_sum_partials, dim3(kBiasBlocks), dim3(256), 0, st, a.d_fused, (int64_t)a.N * a.H * a.W,
                            wsf + off[4]);
         FOSVOS_LAUNCH_CHECK();
     }
+    FOSVOS_PROF("k_head_finish", st, 0.0);
     hipLaunchKernelGGL(k_head_finish, dim3(5), dim3(768), 0, st, fa, a.d_fuse_w, a.d_fuse_b,
                        with_so ? a.d_dsn_w : nullptr, with_so ? a.d_dsn_b : nullptr);
     FOSVOS_LAUNCH_CHECK();

@@ -52,10 +52,11 @@ __global__ __launch_bounds__(kBlock) void k_count(const float *__restrict__ labe
 
 __global__ __launch_bounds__(kBlock) void k_loss(const float *__restrict__ x, const float *__restrict__ label,
                                                   int64_t n, int size_average, float grad_scale,
-                                                  float *__restrict__ grad, Ws *ws, int n_count_blocks) {
+                                                  float *__restrict__ grad, Ws *ws, int n_count_blocks,
+                                                  const double *__restrict__ ext_counts) {
     __shared__ double s_pos[kBlock / 64], s_neg[kBlock / 64];
     __shared__ unsigned long long s_np;
-    {   // integer sum of the per-block counts: order-independent, so every block agrees exactly
+    if (!ext_counts) {   // integer sum of the per-block counts: order-independent, so every block agrees exactly
         __shared__ unsigned long long s_c[kBlock / 64];
         unsigned long long c = 0;
         for (int b = threadIdx.x; b < n_count_blocks; b += kBlock) c += ws->count[b];
@@ -66,8 +67,9 @@ __global__ __launch_bounds__(kBlock) void k_loss(const float *__restrict__ x, co
         if (threadIdx.x == 0) s_np = s_c[0] + s_c[1] + s_c[2] + s_c[3];
         __syncthreads();
     }
-    const double n_tot = (double)n;
-    const double n_pos = (double)s_np;
+    // ext_counts (data-parallel batches): {positives, pixels} of the WHOLE batch, counted over all ranks
+    const double n_tot = ext_counts ? ext_counts[1] : (double)n;
+    const double n_pos = ext_counts ? ext_counts[0] : (double)s_np;
     const double n_neg = n_tot - n_pos;
     double gscale = (double)grad_scale;
     if (size_average) gscale /= n_tot;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void k_loss(const float *__restrict__ x, co
 }
 
 __global__ __launch_bounds__(64) void k_finish(int64_t n, int size_average, const Ws *ws, int n_blocks,
-                                                float *__restrict__ loss_out) {
+                                                float *__restrict__ loss_out, const double *__restrict__ ext_counts) {
     // lane t sums entries t, t+64, ... then a fixed butterfly: the order never changes run to run
     unsigned long long np = 0;
     double pos = 0.0, neg = 0.0;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(64) void k_finish(int64_t n, int size_average, cons
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int b = min(b0 + 64 * j, n_blocks - 1);
-            c[j] = ws->count[b];
+            c[j] = ext_counts ? 0ull : ws->count[b];
             p[j] = ws->pos[b];
             q[j] = ws->neg[b];
         }
@@ -145,8 +147,8 @@ __global__ __launch_bounds__(64) void k_finish(int64_t n, int size_average, cons
     pos = wave_sum(pos);
     neg = wave_sum(neg);
     if (threadIdx.x != 0) return;
-    const double n_tot = (double)n;
-    const double n_pos = (double)np, n_neg = n_tot - n_pos;
+    const double n_tot = ext_counts ? ext_counts[1] : (double)n;
+    const double n_pos = ext_counts ? ext_counts[0] : (double)np, n_neg = n_tot - n_pos;
     double loss = n_neg / n_tot * pos + n_pos / n_tot * neg;
     if (size_average) loss /= n_tot;
     *loss_out = (float)loss;
@@ -155,9 +157,10 @@ __global__ __launch_bounds__(64) void k_finish(int64_t n, int size_average, cons
 
 extern "C" size_t fosvos_cbce_workspace_bytes(int64_t) { return sizeof(Ws); }
 
-extern "C" int fosvos_cbce_loss(const float *logits, const float *label, int64_t numel, int size_average,
-                                float grad_scale, float *loss_out, float *grad, void *workspace,
-                                size_t workspace_bytes, int device, void *stream) {
+namespace {
+int cbce_impl(const float *logits, const float *label, int64_t numel, int size_average, float grad_scale,
+              const double *batch_counts, float *loss_out, float *grad, void *workspace, size_t workspace_bytes,
+              int device, void *stream) {
     FOSVOS_REQUIRE(logits && label && loss_out && workspace, FOSVOS_E_ARG, "cbce_loss: null pointer");
     FOSVOS_REQUIRE(numel > 0, FOSVOS_E_SHAPE, "cbce_loss: numel=%lld", (long long)numel);
     FOSVOS_REQUIRE(workspace_bytes >= sizeof(Ws), FOSVOS_E_WORKSPACE, "cbce_loss: workspace %zu < %zu",
@@ -169,12 +172,34 @@ extern "C" int fosvos_cbce_loss(const float *logits, const float *label, int64_t
     if (blocks > kMaxBlocks) blocks = kMaxBlocks;
     Ws *ws = reinterpret_cast<Ws *>(workspace);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_count, dim3(blocks), dim3(kBlock), 0, s, label, numel, ws);
-    FOSVOS_LAUNCH_CHECK();
+    if (!batch_counts) {
+        FOSVOS_PROF("k_count", s, 0.0);
+        hipLaunchKernelGGL(k_count, dim3(blocks), dim3(kBlock), 0, s, label, numel, ws);
+        FOSVOS_LAUNCH_CHECK();
+    }
+    FOSVOS_PROF("k_loss", s, 0.0);
     hipLaunchKernelGGL(k_loss, dim3(blocks), dim3(kBlock), 0, s, logits, label, numel, size_average, grad_scale, grad,
-                       ws, blocks);
+                       ws, blocks, batch_counts);
     FOSVOS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, s, numel, size_average, ws, blocks, loss_out);
+    FOSVOS_PROF("k_finish", s, 0.0);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, s, numel, size_average, ws, blocks, loss_out, batch_counts);
     FOSVOS_LAUNCH_CHECK();
     return FOSVOS_OK;
+}
+}  // namespace
+
+extern "C" int fosvos_cbce_loss(const float *logits, const float *label, int64_t numel, int size_average,
+                                float grad_scale, float *loss_out, float *grad, void *workspace,
+                                size_t workspace_bytes, int device, void *stream) {
+    return cbce_impl(logits, label, numel, size_average, grad_scale, nullptr, loss_out, grad, workspace, workspace_bytes,
+                     device, stream);
+}
+
+extern "C" int fosvos_cbce_loss_batch_counts(const float *logits, const float *label, int64_t numel, int size_average,
+                                             float grad_scale, const double *batch_counts, float *loss_out,
+                                             float *grad, void *workspace, size_t workspace_bytes, int device,
+                                             void *stream) {
+    FOSVOS_REQUIRE(batch_counts, FOSVOS_E_ARG, "cbce_loss_batch_counts: null batch_counts");
+    return cbce_impl(logits, label, numel, size_average, grad_scale, batch_counts, loss_out, grad, workspace,
+                     workspace_bytes, device, stream);
 }

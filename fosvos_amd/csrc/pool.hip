@@ -111,6 +111,7 @@ extern "C" int fosvos_maxpool2x2_ceil_fwd(const uint16_t *x, uint16_t *y, int N,
     FOSVOS_ENTER(device);
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;
     const int64_t total = (int64_t)N * OH * OW * (C / 8);
+    FOSVOS_PROF("k_pool_fwd", stream, 0.0);
     hipLaunchKernelGGL(k_pool_fwd, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, OH, OW, total);
     FOSVOS_LAUNCH_CHECK();
     return FOSVOS_OK;
@@ -124,6 +125,7 @@ extern "C" int fosvos_maxpool2x2_ceil_bwd(const uint16_t *x, const uint16_t *dy,
     FOSVOS_ENTER(device);
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;
     const int64_t total = (int64_t)N * OH * OW * (C / 8);
+    FOSVOS_PROF("k_pool_bwd", stream, 0.0);
     hipLaunchKernelGGL(k_pool_bwd, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, H, W, C, OH, OW,
                        relu_mask, total);
     FOSVOS_LAUNCH_CHECK();

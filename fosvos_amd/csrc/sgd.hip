@@ -52,6 +52,7 @@ extern "C" int fosvos_sgd_momentum_step(const fosvos_sgd_entry *table, int n_ten
     FOSVOS_ENTER(device);
     int64_t gx = cdiv(max_numel, 256 * 4);
     if (gx > 512) gx = 512;
+    FOSVOS_PROF("k_sgd", stream, 0.0);
     hipLaunchKernelGGL(k_sgd, dim3((unsigned)gx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream, table,
                        momentum, first_step);
     FOSVOS_LAUNCH_CHECK();

@@ -9,6 +9,101 @@ thread_local char g_err[512] = "";
 using namespace fosvos;
 
 extern "C" int fosvos_abi_version(void) { return FOSVOS_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------ launch profiler
+// Timing events around every kernel launch, on the stream the kernel is launched on (the two-stream backward has two).
+// Events exist only between fosvos_profile_start and fosvos_profile_stop; nothing is allocated otherwise.
+#include <mutex>
+#include <vector>
+namespace fosvos {
+bool g_prof_on = false;
+namespace {
+struct ProfLaunch {
+    const char *name;
+    double flops;
+};
+std::mutex g_prof_mutex;
+std::vector<hipEvent_t> g_prof_events;   // 2 per launch slot
+std::vector<ProfLaunch> g_prof_launches;
+int g_prof_device = -1;
+thread_local int t_prof_open = -1;       // slot whose stop event is still to be recorded by this thread
+thread_local hipStream_t t_prof_stream = nullptr;
+}  // namespace
+
+void prof_begin(const char *name, hipStream_t st, double flops) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    t_prof_open = -1;
+    const size_t slot = g_prof_launches.size();
+    if (!g_prof_on || 2 * slot + 1 >= g_prof_events.size()) return;  // capacity reached: later launches go untimed
+    g_prof_launches.push_back({name, flops});
+    if (hipEventRecord(g_prof_events[2 * slot], st) != hipSuccess) {
+        g_prof_launches.pop_back();
+        return;
+    }
+    t_prof_open = (int)slot;
+    t_prof_stream = st;
+}
+
+void prof_end() {
+    if (t_prof_open < 0) return;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    if (g_prof_on && 2 * (size_t)t_prof_open + 1 < g_prof_events.size())
+        (void)hipEventRecord(g_prof_events[2 * t_prof_open + 1], t_prof_stream);
+    t_prof_open = -1;
+}
+}  // namespace fosvos
+
+extern "C" int fosvos_profile_start(int device, int max_launches) {
+    FOSVOS_REQUIRE(max_launches > 0 && max_launches <= (1 << 20), FOSVOS_E_ARG, "profile_start: max_launches=%d", max_launches);
+    FOSVOS_ENTER(device);
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    FOSVOS_REQUIRE(!g_prof_on && g_prof_events.empty(), FOSVOS_E_ARG, "profile_start: a profile is already running");
+    g_prof_events.resize(2 * (size_t)max_launches);
+    for (size_t i = 0; i < g_prof_events.size(); ++i) {
+        if (hipEventCreate(&g_prof_events[i]) != hipSuccess) {
+            for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(g_prof_events[j]);
+            g_prof_events.clear();
+            return fail(FOSVOS_E_HIP, "profile_start: hipEventCreate failed at event %zu", i);
+        }
+    }
+    g_prof_launches.clear();
+    g_prof_launches.reserve(max_launches);
+    g_prof_device = device;
+    g_prof_on = true;
+    return FOSVOS_OK;
+}
+
+extern "C" int fosvos_profile_stop(int device, fosvos_profile_record *out, int capacity, int *n_out) {
+    FOSVOS_REQUIRE(out && n_out && capacity > 0, FOSVOS_E_ARG, "profile_stop: null output");
+    FOSVOS_ENTER(device);
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    FOSVOS_REQUIRE(g_prof_on && device == g_prof_device, FOSVOS_E_ARG, "profile_stop: no profile running on device %d", device);
+    g_prof_on = false;
+    int rc = FOSVOS_OK;
+    if (hipDeviceSynchronize() != hipSuccess) rc = fail(FOSVOS_E_HIP, "profile_stop: hipDeviceSynchronize failed");
+    int n = 0;
+    for (size_t i = 0; rc == FOSVOS_OK && i < g_prof_launches.size(); ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof_events[2 * i], g_prof_events[2 * i + 1]) != hipSuccess) continue;
+        int k = 0;
+        while (k < n && strncmp(out[k].name, g_prof_launches[i].name, sizeof(out[k].name) - 1) != 0) ++k;
+        if (k == n) {
+            if (n == capacity) continue;  // more distinct kernels than the caller has room for
+            memset(&out[n], 0, sizeof(out[n]));
+            strncpy(out[n].name, g_prof_launches[i].name, sizeof(out[n].name) - 1);
+            ++n;
+        }
+        out[k].launches += 1;
+        out[k].ms += ms;
+        out[k].flops += g_prof_launches[i].flops;
+    }
+    for (hipEvent_t e : g_prof_events) (void)hipEventDestroy(e);
+    g_prof_events.clear();
+    g_prof_launches.clear();
+    g_prof_device = -1;
+    *n_out = n;
+    return rc;
+}
 extern "C" const char *fosvos_last_error(void) { return fosvos::g_err; }
 extern "C" const char *fosvos_build_arch(void) { return "gfx950"; }
 
@@ -81,6 +176,7 @@ extern "C" int fosvos_nchw_f32_to_nhwc_bf16(const float *src, uint16_t *dst, int
                    "nchw_f32_to_nhwc_bf16: bad shape N=%d C=%d H=%d W=%d Cpad=%d", N, C, H, W, Cpad);
     FOSVOS_ENTER(device);
     const int64_t total = (int64_t)N * H * W * (Cpad / 8);
+    FOSVOS_PROF("k_nchw_f32_to_nhwc_bf16", stream, 0.0);
     hipLaunchKernelGGL(k_nchw_f32_to_nhwc_bf16, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
                        H * W, Cpad, total);
     FOSVOS_LAUNCH_CHECK();
@@ -212,6 +308,7 @@ extern "C" int fosvos_pack_conv3x3_weights_multi(const fosvos_pack_entry *entrie
     }
     t.block_begin[n] = blocks;
     FOSVOS_ENTER(device);
+    FOSVOS_PROF("k_pack_w_tiled", stream, 0.0);
     hipLaunchKernelGGL(k_pack_w_tiled, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
     FOSVOS_LAUNCH_CHECK();
     return FOSVOS_OK;

@@ -81,15 +81,18 @@ Arena make_arena(int N, int H, int W) {
 }
 
 // ---- the library's only persistent state: timing-disabled events for the two-stream backward
-constexpr int kNEvents = 19;  // 13 conv-output gradients + head + fork + join + d_side[0..2] (aux -> main)
+// 13 conv-output gradients + head + fork + join + d_side[0..2] (aux -> main) + 3 gradient-bucket events (19..21)
+constexpr int kNEvents = 22;
+constexpr int kBucketEvent0 = 19;
 struct EventPool {
     hipEvent_t ev[kNEvents];
     bool ready = false;
+    bool buckets_recorded = false;  // the last backward on this device published its gradient buckets
 };
 EventPool g_events[16];  // per device
 std::mutex g_events_mutex;
 
-int get_events(int device, hipEvent_t **out) {
+int get_events(int device, hipEvent_t **out, EventPool **pool_out = nullptr) {
     FOSVOS_REQUIRE(device >= 0 && device < 16, FOSVOS_E_ARG, "vgg_backward: device index %d out of range", device);
     std::lock_guard<std::mutex> lock(g_events_mutex);
     EventPool &p = g_events[device];
@@ -98,6 +101,7 @@ int get_events(int device, hipEvent_t **out) {
         p.ready = true;
     }
     *out = p.ev;
+    if (pool_out) *pool_out = &p;
     return FOSVOS_OK;
 }
 
@@ -185,9 +189,15 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
     const bool par = aux_stream != nullptr && aux_stream != stream;
     hipStream_t sa = par ? (hipStream_t)aux_stream : sm;
     hipEvent_t *ev = nullptr;
-    if (par) {
+    EventPool *pool = nullptr;
+    const bool buckets = g->bucket_events != 0;
+    if (par || buckets) {
         FOSVOS_ENTER(device);
-        FOSVOS_TRY(get_events(device, &ev));
+        FOSVOS_TRY(get_events(device, &ev, &pool));
+        std::lock_guard<std::mutex> lock(g_events_mutex);
+        pool->buckets_recorded = false;
+    }
+    if (par) {
         // fork: the wgrad stream may not run ahead of what `stream` has queued (the forward pass, the loss)
         FOSVOS_HIP_CHECK(hipEventRecord(ev[14], sm));
         FOSVOS_HIP_CHECK(hipStreamWaitEvent(sa, ev[14], 0));
@@ -270,11 +280,37 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
             FOSVOS_TRY(fosvos_maxpool2x2_ceil_bwd(act(kLastOfStage[s - 1]), reinterpret_cast<const uint16_t *>(base + a.gpooled[s - 1]),
                                                   gact(kLastOfStage[s - 1]), N, a.sh[s - 1], a.sw[s - 1], kStageCh[s - 1], 1,
                                                   device, sm));
+        if (buckets && s >= 3) {
+            // data-parallel step: the gradients of stage 5 (bucket 0) and stage 4 (bucket 1) - 87 % of the bytes - are
+            // finished and published here, so their all-reduce runs under the rest of the backward pass
+            FOSVOS_TRY(wgrad_reduce_all(&reduce, device, sa));
+            FOSVOS_HIP_CHECK(hipEventRecord(ev[kBucketEvent0 + (4 - s)], sa));
+        }
     }
-    FOSVOS_TRY(wgrad_reduce_all(&reduce, device, sa));  // slabs -> dw / db for all 17 layers
+    FOSVOS_TRY(wgrad_reduce_all(&reduce, device, sa));  // slabs -> dw / db for all (remaining) layers
+    if (buckets) {
+        FOSVOS_HIP_CHECK(hipEventRecord(ev[kBucketEvent0 + 2], sa));  // buckets 2 and 3: everything
+        std::lock_guard<std::mutex> lock(g_events_mutex);
+        pool->buckets_recorded = true;
+    }
     if (par && !g->defer_join) {  // join: everything after this call on `stream` sees the weight gradients
         FOSVOS_HIP_CHECK(hipEventRecord(ev[15], sa));
         FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[15], 0));
     }
+    return FOSVOS_OK;
+}
+
+extern "C" int fosvos_vgg_grad_bucket_wait(int device, int bucket, void *stream) {
+    FOSVOS_REQUIRE(bucket >= 0 && bucket < 4, FOSVOS_E_ARG, "vgg_grad_bucket_wait: bucket %d not in 0..3", bucket);
+    FOSVOS_ENTER(device);
+    hipEvent_t *ev = nullptr;
+    EventPool *pool = nullptr;
+    FOSVOS_TRY(get_events(device, &ev, &pool));
+    {
+        std::lock_guard<std::mutex> lock(g_events_mutex);
+        FOSVOS_REQUIRE(pool->buckets_recorded, FOSVOS_E_ARG,
+                       "vgg_grad_bucket_wait: the last fosvos_vgg_backward on device %d did not set grads.bucket_events", device);
+    }
+    FOSVOS_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ev[kBucketEvent0 + (bucket < 2 ? bucket : 2)], 0));
     return FOSVOS_OK;
 }

@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 CONV_RELU = 1
 CONV_OUT_F32 = 2
 
@@ -45,7 +45,12 @@ class VggGrads(ctypes.Structure):
     """fosvos_vgg_grads."""
     _fields_ = [("conv_w", _P13), ("conv_b", _P13), ("side_w", _P4), ("side_b", _P4),
                 ("dsn_w", c_void_p), ("dsn_b", c_void_p), ("fuse_w", c_void_p), ("fuse_b", c_void_p),
-                ("accumulate", c_int), ("defer_join", c_int)]
+                ("accumulate", c_int), ("defer_join", c_int), ("bucket_events", c_int)]
+
+class ProfileRecord(ctypes.Structure):
+    """fosvos_profile_record."""
+    _fields_ = [("name", ctypes.c_char * 96), ("launches", c_int), ("ms", ctypes.c_double), ("flops", ctypes.c_double)]
+
 
 class PackEntry(ctypes.Structure):
     """fosvos_pack_entry."""
@@ -117,6 +122,8 @@ SIGNATURES = {
     "fosvos_cbce_loss": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
                                  c_int, c_void_p]),
     "fosvos_cbce_workspace_bytes": (c_size_t, [c_int64]),
+    "fosvos_cbce_loss_batch_counts": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_size_t, c_int, c_void_p]),
     "fosvos_sgd_momentum_step": (c_int, [c_void_p, c_int, c_int64, c_float, c_int, c_int, c_void_p]),
     "fosvos_conv3x3_s2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_uint,
                                       c_void_p, c_size_t, c_int, c_void_p]),
@@ -145,6 +152,9 @@ SIGNATURES = {
     "fosvos_resnet_forward": (c_int, [POINTER(ResnetNet), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                       POINTER(c_void_p), c_int, c_void_p, c_void_p]),
     "fosvos_vgg_arena_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "fosvos_vgg_grad_bucket_wait": (c_int, [c_int, c_int, c_void_p]),
+    "fosvos_profile_start": (c_int, [c_int, c_int]),
+    "fosvos_profile_stop": (c_int, [c_int, POINTER(ProfileRecord), c_int, POINTER(c_int)]),
     "fosvos_vgg_forward": (c_int, [POINTER(VggWeights), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                    POINTER(c_void_p), c_int, c_void_p]),
     "fosvos_vgg_backward": (c_int, [POINTER(VggWeights), POINTER(VggGrads), c_void_p, c_int, c_int, c_int, c_void_p,
@@ -183,6 +193,27 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().fosvos_last_error()
         raise FosvosHipError(f"{what} failed (code {rc}): {msg.decode(errors='replace') if msg else ''}")
+
+
+class LaunchProfile:
+    """``with LaunchProfile(device_index) as prof: ...`` brackets every kernel the library launches inside the block
+    with timing events on its own launch stream; afterwards ``prof.records`` maps kernel name -> dict(launches, ms,
+    flops)."""
+
+    def __init__(self, device: int, max_launches: int = 65536):
+        self.device, self.max_launches, self.records = int(device), int(max_launches), {}
+
+    def __enter__(self):
+        check(lib().fosvos_profile_start(self.device, self.max_launches), "profile_start")
+        return self
+
+    def __exit__(self, *exc):
+        buf = (ProfileRecord * 128)()
+        n = c_int(0)
+        check(lib().fosvos_profile_stop(self.device, buf, 128, ctypes.byref(n)), "profile_stop")
+        self.records = {buf[i].name.decode(): {"launches": buf[i].launches, "ms": buf[i].ms, "flops": buf[i].flops}
+                        for i in range(n.value)}
+        return False
 
 
 def ptr_array4(ptrs) -> "ctypes.Array":

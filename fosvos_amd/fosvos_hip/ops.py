@@ -442,9 +442,14 @@ def head_bwd(side: Sequence[torch.Tensor], filt: Sequence[torch.Tensor], filt1: 
 
 # ------------------------------------------------------------------------------------------ loss
 def cbce_loss(logits: torch.Tensor, label: torch.Tensor, size_average: bool = True, grad_scale: float = 1.0,
-              want_grad: bool = True):
-    """Returns (loss: 0-dim fp32 tensor on the device, grad like logits or None)."""
+              want_grad: bool = True, batch_counts: Optional[torch.Tensor] = None):
+    """Returns (loss: 0-dim fp32 tensor on the device, grad like logits or None).  batch_counts: device float64 [2]
+    {positives, pixels} of the whole (data-parallel) batch this tensor is a shard of; None = count this tensor."""
     _need(logits, _F32, "cbce_loss logits"); _need(label, _F32, "cbce_loss label")
+    if batch_counts is not None:
+        if (not batch_counts.is_cuda or batch_counts.dtype != torch.float64 or batch_counts.numel() != 2
+                or not batch_counts.is_contiguous()):
+            raise ValueError("cbce_loss: batch_counts must be a contiguous float64 [2] tensor on the GPU")
     if logits.shape != label.shape:
         raise ValueError(f"cbce_loss: logits {tuple(logits.shape)} vs label {tuple(label.shape)}")
     L = lib()
@@ -455,8 +460,13 @@ def cbce_loss(logits: torch.Tensor, label: torch.Tensor, size_average: bool = Tr
     ws, wsn = _WS.get(L.fosvos_cbce_workspace_bytes(logits.numel()), logits.device)
     dev, st = _ctx(logits)
     t0 = _pb()
-    check(L.fosvos_cbce_loss(logits.data_ptr(), label.data_ptr(), logits.numel(), 1 if size_average else 0,
-                             float(grad_scale), loss.data_ptr(), _p(grad), ws, wsn, dev, st), "cbce_loss")
+    if batch_counts is None:
+        check(L.fosvos_cbce_loss(logits.data_ptr(), label.data_ptr(), logits.numel(), 1 if size_average else 0,
+                                 float(grad_scale), loss.data_ptr(), _p(grad), ws, wsn, dev, st), "cbce_loss")
+    else:
+        check(L.fosvos_cbce_loss_batch_counts(logits.data_ptr(), label.data_ptr(), logits.numel(),
+                                              1 if size_average else 0, float(grad_scale), batch_counts.data_ptr(),
+                                              loss.data_ptr(), _p(grad), ws, wsn, dev, st), "cbce_loss_batch_counts")
     _pe(t0, "cbce_loss", 0.0, logits.numel() * (16 if want_grad else 12))
     return loss, grad
 

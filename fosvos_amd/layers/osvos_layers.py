@@ -29,9 +29,10 @@ class _CBCELoss(torch.autograd.Function):
     """Loss value and d(loss)/d(logits) come out of the same kernel pass; backward only scales."""
 
     @staticmethod
-    def forward(ctx, output, label, size_average):
+    def forward(ctx, output, label, size_average, batch_counts=None):
         loss, grad = ops.cbce_loss(output.contiguous().float(), label.contiguous().float(),
-                                   size_average=bool(size_average), want_grad=output.requires_grad)
+                                   size_average=bool(size_average), want_grad=output.requires_grad,
+                                   batch_counts=batch_counts)
         ctx.grad = grad
         ctx.shape = output.shape
         return loss
@@ -39,16 +40,20 @@ class _CBCELoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if ctx.grad is None:
-            return None, None, None
-        return (ctx.grad * g).reshape(ctx.shape), None, None
+            return None, None, None, None
+        return (ctx.grad * g).reshape(ctx.shape), None, None, None
 
 
-def class_balanced_cross_entropy_loss(output, label, size_average=True):
+def class_balanced_cross_entropy_loss(output, label, size_average=True, batch_counts=None):
     """Class-balanced cross entropy loss (same contract as the reference).
 
     Args:
     output: Output of the network (logits)
     label: Ground truth label
+    batch_counts: (extension, data-parallel training only) float64 [2] device tensor {positives, pixels} of the WHOLE
+        batch when ``output`` is one rank's shard of it (``parallel.batch_label_counts``): the reference balances the
+        classes over the batch tensor (src/layers/osvos_layers.py:28-39), so a shard needs the batch's counts for the
+        ranks' losses to add up to the single-process value.  None: count ``label`` itself (the reference's behaviour).
     Returns:
     0-dim tensor with the loss; reductions run over the whole batch tensor."""
     if not output.is_cuda:
@@ -59,7 +64,7 @@ def class_balanced_cross_entropy_loss(output, label, size_average=True):
     if tuple(label.shape) != tuple(output.shape):
         raise ValueError("class_balanced_cross_entropy_loss: output {} vs label {}".format(
             tuple(output.shape), tuple(label.shape)))
-    return _CBCELoss.apply(output, label, size_average)
+    return _CBCELoss.apply(output, label, size_average, batch_counts)
 
 
 def crop_offsets(size, target):

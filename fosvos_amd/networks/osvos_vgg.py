@@ -87,6 +87,26 @@ class OSVOS_VGG(nn.Module):
             self._packs.arenas.join()
         self._packs.defer_wgrad_join = bool(value)
 
+    @property
+    def publish_grad_buckets(self):
+        return getattr(self._packs, "publish_grad_buckets", False)
+
+    @publish_grad_buckets.setter
+    def publish_grad_buckets(self, value):
+        """True: backward passes publish their gradients in completion order (stage 5, stage 4, the rest) through
+        ``wait_grad_bucket`` - what the data-parallel loops overlap their bucketed all-reduce with."""
+        self._packs.publish_grad_buckets = bool(value)
+
+    def wait_grad_bucket(self, bucket, stream=None):
+        """Make `stream` (default: the current one) wait for gradient bucket `bucket` (``parallel.VGG_BUCKETS`` order) of
+        the last backward pass run with ``publish_grad_buckets``; returns at once on the host."""
+        import torch
+        from fosvos_hip import check, lib
+        dev = next(self.parameters()).device
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        st = stream if stream is not None else torch.cuda.current_stream(idx)
+        check(lib().fosvos_vgg_grad_bucket_wait(idx, int(bucket), st.cuda_stream), "vgg_grad_bucket_wait")
+
     def _ordered_params(self):
         """The 52 parameters in state_dict order, by direct attribute access (named_parameters() walks the whole
         module tree: 0.15 ms per call)."""

@@ -10,13 +10,20 @@ independent processes that shard the sequence list (src/train_online.py:184-186)
   step; with ``world * local_accum == avg_grad_every_n`` this reproduces the single-process update
   (src/train_online.py:92-101) up to fp32 summation order.
 
-Gradients live in ONE flat fp32 buffer (each ``p.grad`` is a view), so the all-reduce is a single
-59.7 MB collective instead of 26 small ones, and zeroing is one memset.
+Gradients live in ONE flat fp32 buffer (each ``p.grad`` is a view), so zeroing is one memset and a collective
+covers a contiguous slice.  The all-reduce is BUCKETED in the order the backward pass finishes gradients (stage 5
+first): ``FlatGrads.all_reduce_begin`` issues one asynchronous all-reduce per bucket, each waiting only for ITS
+gradients (the native backward publishes an event per bucket, ``fosvos_vgg_grad_bucket_wait``), so the large
+stage-5 / stage-4 transfers run under the rest of the backward pass; ``all_reduce_finish`` joins them in front of
+the optimizer step.  Frozen tensors (the bilinear deconvs, lr 0, no gradient is ever produced) are not sent.
+
+Offline training over a split batch also needs the class counts of the WHOLE batch (the reference balances classes
+over the batch tensor, src/layers/osvos_layers.py:28-39): ``batch_label_counts``.
 """
 from __future__ import annotations
 
 import os
-from typing import Iterable, List, Optional, Sequence
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -61,11 +68,32 @@ def split_accumulation(avg_grad_every_n: int, world: int) -> int:
     return avg_grad_every_n // world
 
 
+# Gradient buckets in the order the backward pass completes them, by parameter-name prefix (state_dict names of
+# OSVOS_VGG).  Bucket index = the `bucket` argument of fosvos_vgg_grad_bucket_wait.
+VGG_BUCKETS = (("stages.4.",), ("stages.3.",), ("stages.0.", "stages.1.", "stages.2."),
+               ("side_prep.", "score_dsn.", "fuse."))
+
+
+def batch_label_counts(gts: torch.Tensor) -> Optional[torch.Tensor]:
+    """float64 [2] {positives, pixels} of the data-parallel batch `gts` is this rank's shard of (SUM over ranks);
+    None in a single process (the loss then counts its own tensor, as the reference does)."""
+    if world_size() == 1:
+        return None
+    counts = torch.stack([(gts >= 0.5).sum().to(torch.float64),
+                          torch.tensor(float(gts.numel()), dtype=torch.float64, device=gts.device)])
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    return counts
+
+
 class FlatGrads:
     """All trainable gradients as views of one flat fp32 buffer."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], names: Optional[Sequence[str]] = None,
+                 buckets: Sequence[Sequence[str]] = VGG_BUCKETS, frozen: Sequence[str] = ("upscale.", "upscale_.")):
         params = list(params)
+        names = list(names) if names is not None else None
+        if names is not None and len(names) != len(params):
+            raise ValueError("FlatGrads: names and params differ in length")
         # re-use the buffer a previous loop already attached to these parameters
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
@@ -81,12 +109,104 @@ class FlatGrads:
         self.numel = total
         for p, o in zip(self.params, offs):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
+        # bucket b = one contiguous slice [lo, hi) of the flat buffer; without names: one bucket, everything.
+        # Trainable tensors outside every bucket form trailing buckets of their own, except those under `frozen`:
+        # the engine never produces a gradient for them (the reference keeps them at lr 0), their slice stays zero.
+        self.slices: List[Tuple[int, int]] = [(0, cur)]
+        if names is not None:
+            trainable = [n for n, p in zip(names, params) if p.requires_grad]
+            ends = offs[1:] + [cur]
+            self.slices = []
+            covered = set()
+            for prefixes in buckets:
+                idx = [i for i, n in enumerate(trainable) if n.startswith(tuple(prefixes))]
+                if not idx:
+                    continue
+                if idx != list(range(idx[0], idx[-1] + 1)):
+                    raise ValueError(f"FlatGrads: bucket {prefixes} is not contiguous in parameter order")
+                self.slices.append((offs[idx[0]], ends[idx[-1]]))
+                covered.update(idx)
+            run: List[int] = []
+            for i, n in enumerate(trainable + [None]):
+                if n is not None and i not in covered and not n.startswith(tuple(frozen)):
+                    run.append(i)
+                elif run:
+                    self.slices.append((offs[run[0]], ends[run[-1]]))
+                    run = []
+        self._works: list = []
 
     def zero(self) -> None:
         self.flat.zero_()
 
     def all_reduce(self, async_op: bool = False):
-        """SUM over ranks (no-op in a single process)."""
+        """SUM of the whole buffer over ranks in one collective (no-op in a single process)."""
         if world_size() == 1:
             return None
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+
+    def all_reduce_begin(self, wait_bucket: Optional[Callable[[int], None]] = None) -> None:
+        """One asynchronous SUM all-reduce per bucket, in completion order.  `wait_bucket(b)` is called right before
+        bucket b's collective is enqueued and must make the CURRENT stream wait for that bucket's gradients (on the
+        HIP path: fosvos_vgg_grad_bucket_wait on the communication stream); None = the current stream already
+        follows the whole backward pass."""
+        if world_size() == 1:
+            return
+        for b, (lo, hi) in enumerate(self.slices):
+            if wait_bucket is not None:
+                wait_bucket(b)
+            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def all_reduce_finish(self) -> None:
+        """Make the current stream (the host, for CPU tensors) wait for every collective of all_reduce_begin."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+
+class GradSync:
+    """The gradient exchange of one optimizer step in the data-parallel loops (train_online / train_offline):
+
+        sync.arm()                  before the LAST backward of the accumulation cycle
+        loss.backward(...)
+        sync.begin()                right after it: bucketed asynchronous all-reduce on a communication stream
+        ...
+        sync.finish()               in front of optimizer.step(): the current stream waits for all of it
+
+    On the GPU each bucket's collective waits only for that bucket's gradients (``net.wait_grad_bucket``), so the
+    stage-5 and stage-4 transfers (87 % of the bytes) run under the rest of the backward pass.  With CPU tensors (gloo
+    tests) the same calls run the same bucketed arithmetic without streams."""
+
+    def __init__(self, net, flat: "FlatGrads"):
+        self.net, self.flat = net, flat
+        self.active = world_size() > 1
+        self._comm = None
+
+    def arm(self) -> None:
+        if self.active and hasattr(self.net, "publish_grad_buckets"):
+            self.net.publish_grad_buckets = True
+
+    def begin(self) -> None:
+        if not self.active:
+            return
+        net = self.net
+        if hasattr(net, "publish_grad_buckets"):
+            net.publish_grad_buckets = False
+        if self.flat.flat.is_cuda and hasattr(net, "wait_grad_bucket"):
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=self.flat.flat.device)
+            main = torch.cuda.current_stream(self.flat.flat.device)
+            comm = self._comm
+
+            def wait(b: int) -> None:
+                net.wait_grad_bucket(b, comm)
+                if b >= 2:  # the tail buckets also hold gradients the host side adds on the main stream (score_dsn)
+                    comm.wait_stream(main)
+
+            with torch.cuda.stream(comm):
+                self.flat.all_reduce_begin(wait)
+        else:
+            self.flat.all_reduce_begin(None)
+
+    def finish(self) -> None:
+        if self.active:
+            self.flat.all_reduce_finish()

@@ -32,8 +32,9 @@ def train_and_test(net_provider: NetworkProvider, settings: OfflineSettings) -> 
     io_helper.write_settings(save_dir_models, net_provider.name, settings, variant_offline=settings.variant_offline)
     if settings.is_training:
         net_provider.load_network_train()
+        shard = (parallel.rank(), parallel.world_size()) if data_parallel else None
         data_loader_train = io_helper.get_data_loader_train(db_root_dir, settings.batch_size_train,
-                                                            synthetic=synthetic_size)
+                                                            synthetic=synthetic_size, shard=shard)
         data_loader_test = io_helper.get_data_loader_test(db_root_dir, settings.batch_size_test,
                                                           synthetic=synthetic_size)
         optimizer = net_provider.get_optimizer()
@@ -61,7 +62,11 @@ def _get_summary_writer():
 def _losses(net, minibatch):
     inputs, gts = gpu_handler.cast_cuda_if_possible([minibatch['image'], minibatch['gt']])
     outputs = net.forward(inputs)
-    return [class_balanced_cross_entropy_loss(o, gts, size_average=False) for o in outputs]
+    # Data parallel: this minibatch is one rank's shard of the step's batch.  The reference balances the classes over the
+    # whole batch tensor (src/layers/osvos_layers.py:28-39), so the two counts are summed over the ranks first (one
+    # 16-byte all-reduce, shared by the five losses); the ranks' losses then add up to the single-process value.
+    counts = parallel.batch_label_counts(gts) if data_parallel else None
+    return [class_balanced_cross_entropy_loss(o, gts, size_average=False, batch_counts=counts) for o in outputs]
 
 
 def _train(net_provider: NetworkProvider, data_loader_train, data_loader_test, optimizer: optim.SGD, summary_writer,
@@ -73,14 +78,20 @@ def _train(net_provider: NetworkProvider, data_loader_train, data_loader_test, o
     # weights are constant inside an accumulation cycle: let the next forward overlap the wgrad tail of this backward
     net.defer_wgrad_join = os.environ.get('FOSVOS_DEFER_JOIN', '1') != '0'
     world = parallel.world_size() if data_parallel else 1
-    local_accum = parallel.split_accumulation(avg_grad_every_n, world)
+    # Data parallel here splits the BATCH, not the accumulation: every rank runs all
+    # avg_grad_every_n iterations of a cycle on its own shard of each iteration's batch (global batch = world x
+    # batch_size_train), the class counts of the loss are summed over the ranks per iteration (_losses) and the gradients
+    # once per optimizer step - the update of a single process running the whole batch.
+    local_accum = avg_grad_every_n
     # gradients live in one flat fp32 buffer: the wgrad kernels accumulate straight into it, zeroing is one memset,
     # and under data parallelism it is the single all-reduce payload
-    flat = parallel.FlatGrads(net.parameters())
+    named = list(net.named_parameters())
+    flat = parallel.FlatGrads([p for _, p in named], names=[n for n, _ in named])
+    sync = parallel.GradSync(net, flat)
     device = next(net.parameters()).device
 
     n_samples_train = len(data_loader_train)
-    loss_train, loss_test = [], []
+    loss_train, loss_test, losses_train = [], [], []
     counter_gradient = 0
     n_iters = 0
     time_all_start = timeit.default_timer()
@@ -95,6 +106,7 @@ def _train(net_provider: NetworkProvider, data_loader_train, data_loader_test, o
             if index % n_samples_train == n_samples_train - 1:
                 vals = (running / n_samples_train).tolist()  # one device->host sync per epoch
                 loss_train.append(vals[-1])
+                losses_train.append(vals)  # all five deeply supervised losses of the epoch
                 summary_writer.add_scalar('data/total_loss_epoch', vals[-1], epoch)
                 log.info('[Epoch: %d, numImages: %5d]' % (epoch, index + 1))
                 for l in range(len(vals)):
@@ -103,14 +115,18 @@ def _train(net_provider: NetworkProvider, data_loader_train, data_loader_test, o
 
             # `loss /= nAveGrad; loss.backward()` of the reference, as a backward pass seeded with 1/nAveGrad (same gradient,
             # three fewer tiny kernels: see train_online._train)
+            last_of_cycle = world > 1 and (counter_gradient + 1) % local_accum == 0
+            if last_of_cycle:
+                sync.arm()
             loss.backward(torch.full_like(loss.detach(), 1.0 / avg_grad_every_n))
+            if last_of_cycle:
+                sync.begin()
             counter_gradient += 1
             n_iters += 1
 
             if counter_gradient % local_accum == 0:
                 net.join_gradients()
-                if world > 1:
-                    flat.all_reduce()
+                sync.finish()  # the bucketed all-reduce begun right behind the cycle's last backward pass
                 optimizer.step()
                 flat.zero()
                 counter_gradient = 0
@@ -133,7 +149,7 @@ def _train(net_provider: NetworkProvider, data_loader_train, data_loader_test, o
     net.defer_wgrad_join = False  # joins
     if torch.cuda.is_available():
         torch.cuda.synchronize()
-    return {'loss_train': loss_train, 'loss_test': loss_test, 'iterations': n_iters,
+    return {'loss_train': loss_train, 'loss_test': loss_test, 'losses_train': losses_train, 'iterations': n_iters,
             'seconds': timeit.default_timer() - time_all_start}
 
 

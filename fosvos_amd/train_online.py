@@ -69,6 +69,16 @@ def train_and_test(net_provider: NetworkProvider, seq_name: str, settings: Onlin
                                settings.eval_speeds, seq_name=seq_name)
 
 
+class _Landed:
+    """Stand-in for a recorded CUDA event when the loop runs on CPU tensors."""
+
+    def query(self):
+        return True
+
+    def synchronize(self):
+        pass
+
+
 def _get_summary_writer(seq_name: str):
     return io_helper.get_summary_writer(Path('tensorboard') / path_stem)
 
@@ -85,7 +95,9 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     local_accum = parallel.split_accumulation(avg_grad_every_n, world)
     # gradients live in one flat fp32 buffer: the wgrad kernels accumulate straight into it, zeroing is one memset,
     # and under data parallelism it is the single all-reduce payload
-    flat = parallel.FlatGrads(net.parameters())
+    named = list(net.named_parameters())
+    flat = parallel.FlatGrads([p for _, p in named], names=[n for n, _ in named])
+    sync = parallel.GradSync(net, flat)
 
     n_samples = len(dataloader)
     loss_tr = []
@@ -126,10 +138,13 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             if epoch % log_every == log_every - 1:
                 # the reference reads the running loss here (a device->host sync that drains the launch queue 20 times
                 # per run); the value is copied to pinned memory asynchronously instead and logged once it has landed
-                host_val = torch.empty((), dtype=torch.float32, pin_memory=True)
-                host_val.copy_(running_loss_tr, non_blocking=True)
-                landed = torch.cuda.Event()
-                landed.record()
+                if device.type == 'cuda':
+                    host_val = torch.empty((), dtype=torch.float32, pin_memory=True)
+                    host_val.copy_(running_loss_tr, non_blocking=True)
+                    landed = torch.cuda.Event()
+                    landed.record()
+                else:  # CPU tensors (the gloo tests of the data-parallel wiring): nothing to wait for
+                    host_val, landed = running_loss_tr.clone(), _Landed()
                 pending_logs.append((epoch, minibatch_index, host_val, landed))
                 running_loss_tr.zero_()
                 flush_logs(False)
@@ -137,7 +152,12 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             # reference: `loss /= nAveGrad; loss.backward()` (src/train_online.py:92-93).  Seeding the backward pass with
             # 1/nAveGrad is the same gradient (the division's own backward produces exactly this factor) without the
             # three tiny kernels of the division, the ones-fill and its backward on the critical path
+            last_of_cycle = world > 1 and (counter_gradient + 1) % local_accum == 0
+            if last_of_cycle:
+                sync.arm()
             loss.backward(inv_avg)
+            if last_of_cycle:
+                sync.begin()
             # (the reference also sums loss.item() into a per-epoch tensorboard scalar, src/train_online.py:94-104: one
             # device sync per frame; running_loss_tr above carries the same information without it)
             counter_gradient += 1
@@ -145,8 +165,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
 
             if counter_gradient % local_accum == 0:
                 net.join_gradients()
-                if world > 1:
-                    flat.all_reduce()
+                sync.finish()  # the bucketed all-reduce begun right behind the cycle's last backward pass
                 optimizer.step()
                 flat.zero()
                 counter_gradient = 0

@@ -45,14 +45,22 @@ def write_settings(save_dir: Path, name: str, settings, variant_offline: Optiona
 
 
 def get_data_loader_train(db_root_dir, batch_size: int, seq_name: Optional[str] = None,
-                          synthetic: Optional[Tuple[int, int]] = None) -> DataLoader:
+                          synthetic: Optional[Tuple[int, int]] = None,
+                          shard: Optional[Tuple[int, int]] = None) -> DataLoader:
+    """shard = (rank, world): this process draws its own 1/world of every epoch (data-parallel OFFLINE training, where
+    the ranks split each iteration's batch); None: the reference's single-process loader."""
     if synthetic is not None:
-        ds = SyntheticSequence(seq_name or 'synthetic', synthetic[0], synthetic[1], n_frames=1)
+        ds = SyntheticSequence(seq_name or 'synthetic', synthetic[0], synthetic[1], n_frames=1,
+                               seed=1234 + (shard[0] if shard else 0))
         return DataLoader(ds, batch_size=batch_size, shuffle=True, num_workers=0)
     # src/util/io_helper.py:62-70: random flip, random rescale (ScaleNRotate stays disabled as in the reference), ToTensor
     composed = custom_transforms.Compose([custom_transforms.RandomHorizontalFlip(), custom_transforms.Resize(),
                                           custom_transforms.ToTensor()])
     db_train = DAVIS2016(mode='train', db_root_dir=str(db_root_dir), transform=composed, seq_name=seq_name)
+    if shard is not None:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(db_train, num_replicas=shard[1], rank=shard[0], shuffle=True)
+        return DataLoader(db_train, batch_size=batch_size, sampler=sampler, num_workers=1)
     return DataLoader(db_train, batch_size=batch_size, shuffle=True, num_workers=1)
 
 

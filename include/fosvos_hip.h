@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 8
+#define FOSVOS_ABI_VERSION 9
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -49,6 +49,23 @@ extern "C" {
 #define FOSVOS_CONV_FP32_MATH 4u /* fosvos_conv7x7s2_first_fwd only: fp32 frame and weights on the vector ALU */
 
 int fosvos_abi_version(void);
+
+/* ---- launch profiler --------------------------------------------------------------------------------------------
+ * Between _start and _stop every kernel the library launches (from any entry point, the native layer loops
+ * included) is bracketed by a pair of timing hipEvents recorded on the stream the kernel is launched on, so the
+ * two-stream backward is measured as it ships.  _stop synchronises the device and returns one record per kernel name
+ * (the names rocprofv3 --kernel-trace prints, templates included where several instantiations run): launches, summed
+ * event time in ms, summed algorithmic FLOPs (0 for the byte movers).  The events are created by _start (room for
+ * max_launches launches; later ones go untimed) and destroyed by _stop: the only allocation the library ever makes,
+ * and only on request.  One profile at a time per process. */
+typedef struct fosvos_profile_record {
+    char name[96];
+    int launches;
+    double ms;
+    double flops;
+} fosvos_profile_record;
+int fosvos_profile_start(int device, int max_launches);
+int fosvos_profile_stop(int device, fosvos_profile_record *out, int capacity, int *n_out);
 const char *fosvos_last_error(void);
 /* Name of the gfx target the code object was built for ("gfx950"). */
 const char *fosvos_build_arch(void);
@@ -207,6 +224,14 @@ int fosvos_cbce_loss(const float *logits, const float *label, int64_t numel, int
                      float *loss_out, float *grad, void *workspace, size_t workspace_bytes, int device,
                      void *stream);
 size_t fosvos_cbce_workspace_bytes(int64_t numel);
+/* The same loss on ONE SHARD of a batch that is split over data-parallel ranks.  The reference counts positives /
+ * negatives over the whole batch tensor (src/layers/osvos_layers.py:28-39), so the class weights of a shard must
+ * come from the whole batch: batch_counts = DEVICE double[2] {positives, pixels} summed over all shards (the caller
+ * all-reduces them).  loss_out is this shard's part of the batch loss (the parts add up to it); with size_average the
+ * division is by the batch's pixel count.  grad is what the single-process batch would hold for these pixels. */
+int fosvos_cbce_loss_batch_counts(const float *logits, const float *label, int64_t numel, int size_average,
+                                  float grad_scale, const double *batch_counts, float *loss_out, float *grad,
+                                  void *workspace, size_t workspace_bytes, int device, void *stream);
 
 /* ---- SGD with momentum, torch.optim.SGD semantics, many tensors per launch --------------------
  * For tensor t with n[t] elements: g = grad + wd[t]*p; buf = first_step ? g : momentum*buf + g;
@@ -364,6 +389,9 @@ typedef struct fosvos_vgg_grads {
                                    * end of the call; the caller joins (stream waits on aux_stream) before it reads
                                    * them, and must not reuse this arena before that.  Lets the next forward pass
                                    * (other arena, same weights) overlap the tail of the weight-gradient kernels. */
+    int bucket_events;            /* != 0: publish the gradients in three pieces as the pass finishes them (stage 5,
+                                   * stage 4, the rest) so that a data-parallel caller can start each piece's
+                                   * all-reduce early: see fosvos_vgg_grad_bucket_wait. */
 } fosvos_vgg_grads;
 
 size_t fosvos_vgg_arena_bytes(int N, int H, int W);
@@ -380,6 +408,12 @@ int fosvos_vgg_forward(const fosvos_vgg_weights *w, const float *frame, int N, i
 int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg_grads *g, const float *frame, int N, int H, int W,
                         void *arena, size_t arena_bytes, const float *d_fused, const float *const d_side_out[4],
                         int device, void *stream, void *aux_stream);
+/* Make `stream` wait until gradient bucket `bucket` of the LAST fosvos_vgg_backward on this device (called with
+ * grads.bucket_events != 0) is complete in its buffers: 0 = conv5_1..conv5_3 (stages.4), 1 = conv4_1..conv4_3
+ * (stages.3), 2 = conv1_1..conv3_3, 3 = side_prep / score_dsn / fuse (2 and 3 complete together, at the end of the
+ * pass).  Nothing blocks on the host.  The reference has no collective; this is the hook the
+ * RCCL gradient all-reduce of BASELINE.json's north_star overlaps the backward pass with. */
+int fosvos_vgg_grad_bucket_wait(int device, int bucket, void *stream);
 
 #ifdef __cplusplus
 }

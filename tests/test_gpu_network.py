@@ -173,6 +173,210 @@ def test_online_loop_vs_golden(golden):
                 assert torch.equal(p.detach().cpu(), sd[name])
 
 
+class _NullWriter:
+    def add_scalar(self, *a, **k):
+        pass
+
+    def close(self):
+        pass
+
+
+class _OneShotLoader:
+    """A dataloader whose minibatches come out on the first pass only.  It lets the shipped offline `_train` run
+    exactly ONE epoch of a 240-epoch schedule (the golden trace is epoch 60 of 240: `1 - epoch / n_epochs` needs both
+    numbers), the later epochs iterate over nothing."""
+
+    def __init__(self, batches):
+        self._batches, self._used = list(batches), False
+
+    def __len__(self):
+        return len(self._batches)
+
+    def __iter__(self):
+        if self._used:
+            return iter(())
+        self._used = True
+        return iter(self._batches)
+
+
+def _check_deltas(net, sd, k, prefix, frozen):
+    """Applied weight deltas of EVERY tensor the reference's trace holds (64 strided samples each) against ours."""
+    worst = ("", 0.0)
+    for name, p in net.named_parameters():
+        got_all = p.detach().cpu().double().reshape(-1) - sd[name].double().reshape(-1)
+        idx = torch.from_numpy(k[f"{prefix}_delta_{name}_i"])
+        ref = torch.from_numpy(k[f"{prefix}_delta_{name}_s"]).double()
+        if name.startswith(frozen):
+            assert float(ref.abs().max()) == 0.0 and torch.equal(p.detach().cpu(), sd[name]), name
+            continue
+        scale = ref.abs().max().item()
+        assert scale > 0, name
+        # fp32 masters: an update of lr * grad sits near the fp32 resolution of the weight itself
+        ulp = float(np.spacing(np.float32(max(sd[name].abs().max().item(), 1e-30))))
+        d = got_all[idx] - ref
+        # the stated gradient tolerance (DESIGN.md section 4: rel-L2 <= 0.15 vs the fp32 reference on random weights) over
+        # the tensor's samples, with no single element off by more than twice that share of the largest delta
+        noise = 2 * ulp * float(np.sqrt(d.numel()))
+        ratio = max(d.norm().item() - noise, 0.0) / ref.norm().item()
+        if ratio > worst[1]:
+            worst = (name, ratio)
+        assert ratio <= GRAD_REL_L2, (name, ratio)
+        assert d.abs().max().item() <= 2 * GRAD_REL_L2 * scale + 2 * ulp, (name, d.abs().max().item(), scale, ulp)
+        # moments of the whole delta tensor (sum |d|): direction-free size check of ALL elements, not the samples
+        m_ref = float(k[f"{prefix}_delta_{name}_m"][1])
+        m_got = float(got_all.abs().sum())
+        n_el = got_all.numel()
+        assert abs(m_got - m_ref) <= GRAD_REL_L2 * m_ref + 2 * ulp * n_el, (name, m_got, m_ref)
+    return worst
+
+
+@pytest.mark.parametrize("tag,lr", [("lr1e-8", 1e-8), ("lr1e-9", 1e-9)])
+def test_shipped_online_train_vs_golden(golden, tag, lr):
+    """`train_online._train` ITSELF (FlatGrads views, in-place wgrad accumulation, fused-only head, deferred wgrad
+    join, backward seeded with 1/nAveGrad, FusedSGD) against the trace the reference produced
+    (src/train_online.py:70-107; oracle/make_golden.py section 4): per-iteration losses and the applied weight delta
+    of every tensor."""
+    import train_online
+    from util.network_provider import VGGOnlineProvider
+    k = golden("loops.npz")
+    net, sd = make_net(6)
+    prov = VGGOnlineProvider.__new__(VGGOnlineProvider)
+    prov.network = net
+    prov.name = "vgg16"
+    opt = prov.get_optimizer(learning_rate=lr)
+    frames = [O.synthetic_frame(1, 48, 86, seed=21), O.synthetic_frame(1, 40, 70, seed=22)]
+    loader = [{"image": x, "gt": gt} for x, gt in frames]  # 2 samples per epoch, 5 epochs = the golden's 10 iterations
+    train_online.data_parallel = False
+    ret = train_online._train(prov, loader, opt, _NullWriter(), "golden", 0, 5, 5, 10 ** 9)
+    assert ret["iterations"] == 10
+    # _train logs running_loss / len(dataloader) at every logging point; with 5 epochs every iteration is one
+    trace = np.array(ret["loss"]) * len(loader)
+    np.testing.assert_allclose(trace, k[f"online_{tag}_loss"], rtol=2e-2)
+    worst = _check_deltas(net, sd, k, f"online_{tag}", ("upscale", "score_dsn"))
+    print(f"[online {tag}] worst delta rel-L2 {worst[1]:.3e} at {worst[0]}")
+    # the loop-local switches are restored
+    assert net.compute_side_outputs is True and net.defer_wgrad_join is False
+    outs = net(frames[0][0].to(DEV))
+    assert all(tuple(o.shape) == (1, 1, 48, 86) for o in outs)
+
+
+def test_shipped_offline_train_vs_golden(golden):
+    """`train_offline._train` ITSELF on the golden's schedule (4 iterations of epoch 60 of 240, step every 2, five
+    deeply supervised losses, src/train_offline.py:77-110): the five loss values of the epoch and the applied weight
+    delta of every tensor, score_dsn included."""
+    import train_offline
+    from util.network_provider import VGGOfflineProvider
+    k = golden("loops.npz")
+    net, sd = make_net(8)
+    prov = VGGOfflineProvider.__new__(VGGOfflineProvider)
+    prov.network = net
+    prov.name = "vgg16"
+    opt = prov.get_optimizer(learning_rate=1e-6)
+    x, gt = O.synthetic_frame(2, 33, 47, seed=23)
+    loader = _OneShotLoader([{"image": x, "gt": gt}] * 4)
+    train_offline.data_parallel = False
+    ret = train_offline._train(prov, loader, None, opt, _NullWriter(), 60, 240, 2, 10 ** 9, False, 5)
+    assert ret["iterations"] == 4
+    # the loop logs the epoch mean of each of the five losses; the golden holds them per iteration
+    np.testing.assert_allclose(np.array(ret["losses_train"][0]), k["offline_loss"].mean(axis=0), rtol=3e-2)
+    worst = _check_deltas(net, sd, k, "offline", ("upscale",))
+    print(f"[offline] worst delta rel-L2 {worst[1]:.3e} at {worst[0]}")
+
+
+def test_native_loop_equals_per_op_engine():
+    """The native layer loop (csrc/vgg_net.hip, what ships) and the per-op Python engine (what per-kernel event timing
+    brackets) issue the same kernels with the same launch parameters: logits and every gradient bit for bit."""
+    from fosvos_hip import engine
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    x, gt = O.synthetic_frame(2, 61, 107, seed=51)
+    res = []
+    was = engine.USE_NATIVE_LOOP
+    try:
+        for native in (True, False):
+            engine.USE_NATIVE_LOOP = native
+            net, _ = make_net(14)
+            outs = net(x.to(DEV))
+            ls = [cbce(o, gt.to(DEV), size_average=False) for o in outs]
+            (0.75 * sum(ls[:-1]) + ls[-1]).backward()
+            net.join_gradients()
+            torch.cuda.synchronize()
+            res.append(([o.detach().clone() for o in outs],
+                        {n_: p.grad.clone() for n_, p in net.named_parameters() if p.grad is not None}))
+    finally:
+        engine.USE_NATIVE_LOOP = was
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) > 40
+    for k_ in res[0][1]:
+        assert torch.equal(res[0][1][k_], res[1][1][k_]), k_
+
+
+def test_loss_on_batch_shards_with_batch_counts():
+    """Data-parallel offline training splits a batch over ranks; the reference counts positives / negatives over the
+    WHOLE batch tensor (src/layers/osvos_layers.py:28-39).  With the batch's counts handed in, the shards' losses add
+    up to the single-process loss and every pixel's gradient is bit-identical to the single-process one."""
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    x = torch.randn(4, 1, 33, 47, generator=torch.Generator().manual_seed(3)).to(DEV).requires_grad_(True)
+    _, gt = O.synthetic_frame(4, 33, 47, seed=24)
+    gt = gt.to(DEV)
+    gt[1] = 0  # a shard without positives
+    for size_average in (False, True):
+        full = cbce(x, gt, size_average=size_average)
+        g_full, = torch.autograd.grad(full, x)
+        counts = torch.stack([(gt >= 0.5).sum().double(), torch.tensor(float(gt.numel()), dtype=torch.float64, device=DEV)])
+        parts, grads = [], []
+        for lo in (0, 1, 3):  # ragged shards: 1 + 2 + 1 frames
+            hi = {0: 1, 1: 3, 3: 4}[lo]
+            xs = x[lo:hi].detach().clone().requires_grad_(True)
+            l = cbce(xs, gt[lo:hi], size_average=size_average, batch_counts=counts)
+            parts.append(l)
+            grads.append(torch.autograd.grad(l, xs)[0])
+        assert abs(sum(p.item() for p in parts) - full.item()) <= 1e-5 * abs(full.item())
+        assert torch.equal(torch.cat(grads), g_full)
+    ref = O.cbce_loss(x.detach().cpu(), gt.cpu(), size_average=False)
+    assert abs(cbce(x, gt, size_average=False).item() - ref.item()) <= 1e-5 * abs(ref.item())
+
+
+def test_gradient_buckets_are_published_in_completion_order():
+    """The hook the data-parallel loops overlap their all-reduce with: after a backward pass run with
+    publish_grad_buckets, a side stream that waits for bucket b sees that bucket's final gradients (stage 5 first),
+    and the values equal a plain backward bit for bit; without the flag the wait is refused."""
+    import parallel
+    from fosvos_hip import FosvosHipError
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    x, gt = O.synthetic_frame(1, 61, 107, seed=61)
+    net, _ = make_net(16)
+    net.accumulate_grads_in_place = True
+    cbce(net(x.to(DEV))[-1], gt.to(DEV), size_average=False).backward()
+    net.join_gradients()
+    torch.cuda.synchronize()
+    plain = {n_: p.grad.clone() for n_, p in net.named_parameters() if p.grad is not None}
+    with pytest.raises(FosvosHipError):
+        net.wait_grad_bucket(0)
+    net2, _ = make_net(16)
+    named = list(net2.named_parameters())
+    flat = parallel.FlatGrads([p for _, p in named], names=[n_ for n_, _ in named])
+    net2.accumulate_grads_in_place = True
+    net2.defer_wgrad_join = True
+    net2.publish_grad_buckets = True
+    cbce(net2(x.to(DEV))[-1], gt.to(DEV), size_average=False).backward()
+    side = torch.cuda.Stream()
+    snaps = []
+    with torch.cuda.stream(side):
+        for b, (lo, hi) in enumerate(flat.slices):
+            net2.wait_grad_bucket(b, side)
+            snaps.append(flat.flat[lo:hi].clone())  # ordered behind bucket b's event only
+    side.synchronize()
+    net2.join_gradients()
+    torch.cuda.synchronize()
+    for (lo, hi), snap in zip(flat.slices, snaps):
+        assert torch.equal(snap, flat.flat[lo:hi])
+    for n_, p in net2.named_parameters():
+        if n_ in plain:
+            assert torch.equal(p.grad, plain[n_]), n_
+    net2.defer_wgrad_join = False
+
+
 def test_inplace_grad_accumulation_matches_autograd():
     """accumulate_grads_in_place (wgrad kernels add into p.grad) gives the same gradients as letting autograd
     accumulate, bit for bit for a single backward and to fp32 rounding for two."""
@@ -316,6 +520,55 @@ def test_train_online_entry_point(tmp_path, monkeypatch):
     train_online.train_and_test(prov, "synthetic", settings)
     assert (tmp_path / "out" / "vgg16_synthetic_epoch-9.pth").exists()
     assert len(list((tmp_path / "results" / "vgg16" / "online" / "synthetic").glob("*.png"))) == 4
+
+
+def test_inference_pass_protocol_and_png_values(tmp_path):
+    """SURVEY §8 (f1), src/util/experiment_helper.py:20-80.  (i) eval_speeds: 10 passes over the loader, net.forward
+    bracketed by device syncs, the first minibatch of every pass dropped, no PNG written; (ii) the PNGs: sigmoid of
+    the fused logits stretched to its own range the way scipy.misc.imsave did - exactly what our own logits give,
+    and within the logit tolerance of what the fp32 oracle's logits give."""
+    from PIL import Image
+    from util import experiment_helper, io_helper
+    net, sd = make_net(15)
+
+    class Prov:
+        network = net
+
+    calls = []
+    fwd = net.forward
+
+    def counting_forward(x):
+        calls.append(tuple(x.shape))
+        return fwd(x)
+
+    net.forward = counting_forward
+    loader = io_helper.get_data_loader_test(None, 1, "syn", synthetic=(96, 160), n_frames=4)
+    avg = experiment_helper.test(Prov, loader, tmp_path / "speed", False, True, seq_name="syn")
+    ev = dict(experiment_helper.last_eval)
+    assert len(calls) == 40 and ev["n_runs"] == 10 and ev["n_forward"] == 40
+    assert len(ev["times"]) == 30 == ev["accurate_images"]          # (n_images - 1) * n_runs
+    assert avg == pytest.approx(float(np.mean(ev["times"]))) and 0 < avg < 1.0
+    assert not (tmp_path / "speed").exists()                         # timing mode writes nothing
+
+    calls.clear()
+    assert experiment_helper.test(Prov, loader, tmp_path / "png", False, False, seq_name="syn") is None
+    assert len(calls) == 4
+    pngs = sorted((tmp_path / "png" / "syn").glob("*.png"))
+    assert [p.name for p in pngs] == ["%05d.png" % i for i in range(4)]
+    net.forward = fwd
+    for i, batch in enumerate(loader):
+        got = np.asarray(Image.open(str(pngs[i]))).astype(np.int32)
+        assert got.shape == (96, 160)
+        with torch.no_grad():
+            ours = net(batch["image"].to(DEV))[-1][0, 0].cpu().numpy()
+            ref = O.forward(sd, batch["image"])[-1][0, 0].numpy()
+        assert np.abs(got - experiment_helper.bytescale(1 / (1 + np.exp(-ours))).astype(np.int32)).max() == 0
+        # vs the oracle: a logit error of LOGIT_TOL x range moves a probability by at most a quarter of it (sigmoid
+        # slope), and the stretch to [0, 255] divides by the probability range of the map
+        p_ref = 1 / (1 + np.exp(-ref.astype(np.float64)))
+        bound = 255.0 * 0.25 * LOGIT_TOL * np.abs(ref).max() / (p_ref.max() - p_ref.min())
+        diff = np.abs(got - experiment_helper.bytescale(p_ref).astype(np.int32)).max()
+        assert diff <= np.ceil(2 * bound) + 1, (diff, bound)  # 2x: both ends of the stretch move too
 
 
 def test_train_online_on_a_davis_tree(tmp_path, monkeypatch):

@@ -261,7 +261,7 @@ def test_conv3x3_dgrad_side(ops):
 
 @pytest.mark.parametrize("n,h,w,ci,co", [(1, 64, 96, 64, 64), (1, 61, 107, 64, 128), (2, 30, 54, 128, 64),
                                           (1, 15, 27, 256, 128), (1, 7, 5, 64, 64), (1, 17, 33, 128, 16),
-                                          (1, 120, 214, 64, 64)])
+                                          (1, 120, 214, 64, 64), (1, 30, 54, 512, 512)])
 def test_conv3x3_wgrad(ops, n, h, w, ci, co):
     x = bf(gen(n, ci, h, w, seed=30))
     dy = bf(gen(n, co, h, w, seed=31))

@@ -4,6 +4,7 @@ import os
 import re
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -118,3 +119,12 @@ def test_sequence_sharding_matches_reference_rule():
     assert parallel.split_accumulation(8, 8) == 1 and parallel.split_accumulation(10, 2) == 5
     with pytest.raises(ValueError):
         parallel.split_accumulation(5, 8)
+
+
+def test_png_bytescale_known_answers():
+    """scipy.misc.imsave's scaling (what src/util/experiment_helper.py:64 relied on): stretch to the map's own range,
+    round half up; a constant map becomes zeros."""
+    from util.experiment_helper import bytescale
+    assert bytescale(np.array([[0.2, 0.7], [0.45, 0.2]])).tolist() == [[0, 255], [128, 0]]
+    assert bytescale(np.full((2, 3), 0.37)).tolist() == [[0, 0, 0], [0, 0, 0]]
+    assert bytescale(np.array([[0.0, 1.0, 0.5, 0.25]])).tolist() == [[0, 255, 128, 64]]
