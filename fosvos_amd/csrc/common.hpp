@@ -54,19 +54,22 @@ void prof_end();
         FOSVOS_HIP_CHECK(hipGetLastError());             \
     } while (0)
 
-// Weight-gradient reduction queue (conv_wgrad.hip): the MFMA kernel of a layer writes per-split slabs; the fold /
-// final passes that turn them into dw/db can run right away (reduce == nullptr) or be queued here and run for all
-// layers in two launches (wgrad_reduce_all).  A queued layer's workspace must stay untouched until then.
+// Weight-gradient reduction queue (conv_wgrad.hip): the MFMA kernel of a layer writes one fp32 slab per pixel split, laid
+// out like dw itself; summing them into dw/db can run right away (reduce == nullptr) or be queued here and run for many
+// layers in one launch (wgrad_reduce_all).  A queued layer's workspace must stay untouched until then.
 struct WgradReduceEntry {
-    float *slabs;  // S slabs of 9*Cor*Ci floats, then room for the folded slabs when fold_blocks > 0
-    float *dw, *db;
-    const float *bias_part;
-    int S, S_bias, Co, Cor, Ci, Ci_real, bco, accumulate;
-    int fold_begin, fold_blocks, final_begin, final_blocks;  // block ranges inside the batched launches
+    const float *slabs;      // S slabs of E_pad floats ([Cor][Ci][9]); the first E_real of each are dw's elements
+    float *dw, *db;          // db may be null
+    const float *bias_part;  // [S][Cor]
+    int64_t E_real, E_pad;
+    int S, Co, Cor, accumulate;
+    int block_begin, n_blocks;  // block range inside the batched final launch (n_blocks cover the layer's elements once)
+    int fold_begin, fold_blocks;  // ... inside the batched fold launch (0 blocks: no fold stage, S <= 8)
 };
+constexpr int kWgradReduceMax = 20;
 struct WgradReduceTable {
     int n;
-    WgradReduceEntry e[20];
+    WgradReduceEntry e[kWgradReduceMax];
 };
 int wgrad_impl(const uint16_t *x, const uint16_t *dy, float *dw, float *db, int N, int H, int W, int Ci, int Co,
                int accumulate, void *workspace, size_t workspace_bytes, int device, void *stream,
@@ -75,6 +78,9 @@ int first_wgrad_impl(const float *frame, const uint16_t *dy, float *dw, float *d
                      int accumulate, void *workspace, size_t workspace_bytes, int device, void *stream,
                      WgradReduceTable *reduce);
 int wgrad_reduce_all(WgradReduceTable *reduce, int device, void *stream);
+// queue (or, reduce == nullptr, run) the sum over S slabs of E_pad floats each into dw's E_real floats and db's Co
+int wgrad_queue_reduce(const float *slabs, const float *bias_part, float *dw, float *db, int S, int64_t E_real,
+                       int64_t E_pad, int Co, int Cor, int accumulate, WgradReduceTable *reduce, int device, void *stream);
 // Head backward in pieces, so that vgg_net.hip can put the scales the data-gradient chain does not need yet on the
 // auxiliary stream: check once, then one call per scale (any order, any stream) and the finish pass (after all four).
 struct HeadBwdArgs {

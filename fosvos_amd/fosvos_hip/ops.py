@@ -452,6 +452,11 @@ def cbce_loss(logits: torch.Tensor, label: torch.Tensor, size_average: bool = Tr
             raise ValueError("cbce_loss: batch_counts must be a contiguous float64 [2] tensor on the GPU")
     if logits.shape != label.shape:
         raise ValueError(f"cbce_loss: logits {tuple(logits.shape)} vs label {tuple(label.shape)}")
+    # the kernels read float4: a slice of a batch (one rank's shard, one frame) may start off a 16-byte boundary
+    if logits.data_ptr() % 16:
+        logits = logits.clone()
+    if label.data_ptr() % 16:
+        label = label.clone()
     L = lib()
     loss = torch.empty((), dtype=_F32, device=logits.device)
     grad = torch.empty_like(logits) if want_grad else None

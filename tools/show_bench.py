@@ -1,14 +1,22 @@
-#!/usr/bin/env python3
-"""Pretty-print a bench.py JSON line."""
+"""Pretty-print bench.py JSON lines: python tools/show_bench.py gpurun_out/x.json [...]"""
 import json
 import sys
 
-d = json.load(open(sys.argv[1]))
-print(f"{d['value']:.1f} {d['unit']}  {d['ms_per_step']:.3f} ms/step  n_gpus={d['n_gpus']}")
-r = d.get("roofline")
-if r:
-    print(f"conv family: {r['achieved']:.1f} TFLOP/s = {r['frac']*100:.2f}% of {r['peak']:.0f}; device ms/step all kernels {r['device_ms_per_step_all_kernels']:.3f}")
-    for k, v in r["by_kernel"].items():
-        print(f"  {k:16s} {v['launches_per_step']:5.1f} launches {v['ms_per_step']:8.4f} ms/step {v['avg_us_per_launch']:8.1f} us  tflops={v['tflops']}  GB/s={v['gbs']}")
-if "cpu_baseline" in d:
-    print("cpu_baseline:", d["cpu_baseline"])
+for f in sys.argv[1:]:
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        print(f, "ERR", e)
+        continue
+    r = d.pop("roofline", None)
+    print(f"{f}: {d['value']:.1f} {d['unit']}  {d['ms_per_step']:.4f} ms/step  n_gpus={d['n_gpus']} ranks={d.get('ranks')} "
+          f"backend={d.get('backend')}")
+    for k in ("replicas", "infer", "cpu_baseline"):
+        if k in d:
+            print("  ", k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in d[k].items() if a not in ("protocol", "sample", "parallelism")})
+    if r:
+        bk = r.pop("by_kernel")
+        print("   roofline", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()
+                              if k not in ("traffic_note", "kernel", "measured")})
+        for k, v in bk.items():
+            print(f"     {k[:58]:58s} n={v['launches_per_step']:5.1f} ms/step={v['ms_per_step']:.4f} avg_us={v['avg_us_per_launch']:7.2f} tflops={v['tflops']}")
