@@ -93,15 +93,16 @@ struct Cfg {
     // different banks
     static constexpr int Y_HALF = TPIX * 64 + 64, X_HALF = NPH * 64 + 64;
     static constexpr int Y_BYTES = WCO * Y_HALF, X_BYTES = WCI * X_HALF, BUF_BYTES = Y_BYTES + X_BYTES;
-    static constexpr int Y_IT = TPIX * CHY / 256;                  // staging pieces per thread
-    static constexpr int X_IT = (NPH * CHX + 255) / 256;
+    static constexpr int NT = 64 * WCO * WCI;                       // threads: one wave per 32 x 32 output block
+    static constexpr int Y_IT = TPIX * CHY / NT;                   // staging pieces per thread
+    static constexpr int X_IT = (NPH * CHX + NT - 1) / NT;
     static constexpr int LDS_BYTES = 2 * BUF_BYTES;                // two tile images (double buffer)
-    static_assert(WCO * WCI == 4, "4 waves per workgroup");
-    static_assert(TPIX * CHY % 256 == 0, "dy pieces divide evenly");
+    static_assert(WCO * WCI == 4 || WCO * WCI == 8, "4 or 8 waves per workgroup");
+    static_assert(TPIX * CHY % NT == 0, "dy pieces divide evenly");
 };
 
 template <int WCO, int WCI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_wgrad3x3(const WgArgs a) {
+__global__ __launch_bounds__(64 * WCO * WCI) __attribute__((amdgpu_waves_per_eu(WCO * WCI / 4, 2))) void k_wgrad3x3(const WgArgs a) {
     using C = Cfg<WCO, WCI>;
     extern __shared__ __attribute__((aligned(16))) char smem_w[];
 
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     int y_goff[C::Y_IT], y_lds[C::Y_IT], y_rc[C::Y_IT];
 #pragma unroll
     for (int it = 0; it < C::Y_IT; ++it) {
-        const int i = it * 256 + tid, pix = i / C::CHY, c = i % C::CHY;
+        const int i = it * C::NT + tid, pix = i / C::CHY, c = i % C::CHY;
         const int ty = pix >> 4, tx = pix & 15;
         y_rc[it] = (ty << 16) | tx;
         y_goff[it] = (ty * W + tx) * a.Cy + co0 + c * 8;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     int x_goff[C::X_IT], x_lds[C::X_IT], x_rc[C::X_IT];
 #pragma unroll
     for (int it = 0; it < C::X_IT; ++it) {
-        const int i = it * 256 + tid, pix = i / C::CHX, c = i % C::CHX;
+        const int i = it * C::NT + tid, pix = i / C::CHX, c = i % C::CHX;
         const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
         x_rc[it] = pix < NPH ? ((hy << 16) | hx) : (0x7fff << 16);  // slots past the halo: never in the image, never stored
         x_goff[it] = ((hy - 1) * W + (hx - 1)) * a.Ci + ci0 + c * 8;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     if constexpr ((i_) < C::Y_IT) *reinterpret_cast<uint4 *>((img_) + y_lds[i_]) = py##i_;
 #define FOSVOS_WG_STX(i_, img_)        \
     if constexpr ((i_) < C::X_IT) {    \
-        if ((i_) * 256 + tid < NPH * C::CHX) *reinterpret_cast<uint4 *>((img_) + x_lds[i_]) = px##i_; \
+        if ((i_) * C::NT + tid < NPH * C::CHX) *reinterpret_cast<uint4 *>((img_) + x_lds[i_]) = px##i_; \
     }
 #define FOSVOS_WG_STORE_TILE(img_) \
     { FOSVOS_WG_STY(0, img_) FOSVOS_WG_STY(1, img_) FOSVOS_WG_STY(2, img_) FOSVOS_WG_STY(3, img_) FOSVOS_WG_STX(0, img_) FOSVOS_WG_STX(1, img_) FOSVOS_WG_STX(2, img_) FOSVOS_WG_STX(3, img_) FOSVOS_WG_STX(4, img_) FOSVOS_WG_STX(5, img_) FOSVOS_WG_STX(6, img_) FOSVOS_WG_STX(7, img_) FOSVOS_WG_STX(8, img_) FOSVOS_WG_STX(9, img_) FOSVOS_WG_STX(10, img_) FOSVOS_WG_STX(11, img_) }
@@ -315,14 +316,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
     if (do_bias) {
         // 256 x 8 partials -> BCO channel sums in a fixed order: channel ch = 8 c + e lives in the threads t = c (mod CHY)
-        float *sb = reinterpret_cast<float *>(smem_w);  // [256][9] floats
+        float *sb = reinterpret_cast<float *>(smem_w);  // [NT][9] floats
 #pragma unroll
         for (int e = 0; e < 8; ++e) sb[tid * 9 + e] = bsum[e];
         __syncthreads();
         if (tid < C::BCO && co0 + tid < a.Cor) {
             const int c = tid >> 3, e = tid & 7;
             float acc_b = 0.f;
-            for (int t2 = c; t2 < 256; t2 += C::CHY) acc_b += sb[t2 * 9 + e];
+            for (int t2 = c; t2 < C::NT; t2 += C::CHY) acc_b += sb[t2 * 9 + e];
             a.bias_part[(int64_t)split * a.Cor + co0 + tid] = acc_b;
         }
     }
@@ -425,13 +426,24 @@ int target_blocks() {  // FOSVOS_WGRAD_BLOCKS: lab switch, read once
     static const int v = [] {
         const char *e = getenv("FOSVOS_WGRAD_BLOCKS");
         const int n = e ? atoi(e) : 0;
-        return n > 0 ? n : 256;
+        // 128: the weight-gradient kernels run BESIDE the data-gradient chain (vgg_net.hip) and a CU that hosts one of these
+        // workgroups has room for one igemm workgroup instead of two; alone on the chip 256 is faster (47 vs 66 us at
+        // conv1_2), in the step 128 wins (738 vs 713 frames/s) and halves the slab bytes
+        return n > 0 ? n : 128;
+    }();
+    return v;
+}
+
+int wgrad_waves() {  // FOSVOS_WGRAD_WAVES=8: 128 co x 64 ci eight-wave workgroups where Co allows (lab switch, read once)
+    static const int v = [] {
+        const char *e = getenv("FOSVOS_WGRAD_WAVES");
+        return e && atoi(e) == 8 ? 8 : 4;
     }();
     return v;
 }
 
 struct Plan {
-    int Cor, Cy, side, tiles_x, tiles_y, n_tiles, tps, S;
+    int Cor, Cy, side, wide, tiles_x, tiles_y, n_tiles, tps, S;
     size_t slab_bytes, bias_bytes;
 };
 
@@ -443,7 +455,11 @@ Plan make_plan(int N, int H, int W, int Ci, int Co) {
     p.tiles_x = (int)cdiv(W, 16);
     p.tiles_y = (int)cdiv(H, TH);
     p.n_tiles = p.tiles_x * p.tiles_y * N;
-    const int out_blocks = p.side ? Ci / 128 : (p.Cor / 64) * (Ci / 64);
+    // wide (opt-in): 8-wave workgroups, 128 co x 64 ci, two waves per SIMD.  Measured: 1.55x the per-CU rate of the 4-wave
+    // form alone on the chip, but it owns its CUs (112 KB of LDS, the whole register file) and the data-gradient kernels
+    // beside it lose more than the weight-gradient stream gains: 705 vs 738 frames/s on the fine-tune step
+    p.wide = !p.side && Co % 128 == 0 && wgrad_waves() == 8;
+    const int out_blocks = p.side ? Ci / 128 : (p.Cor / (p.wide ? 128 : 64)) * (Ci / 64);
     int S = (int)cdiv(target_blocks(), out_blocks);
     if (S > p.n_tiles) S = p.n_tiles;
     if (S < 1) S = 1;
@@ -570,9 +586,19 @@ int fosvos::wgrad_impl(const uint16_t *x, const uint16_t *dy, float *dw, float *
 #ifdef FOSVOS_WG_STAMP
     a.stamps = g_wg_stamps;
 #endif
-    static bool once[64][2];  // per device: opt in to the dynamic LDS size
+    static bool once[64][3];  // per device: opt in to the dynamic LDS size
     const double flops = 2.0 * N * H * W * 9.0 * Ci * Co;
-    if (!p.side) {
+    if (p.wide) {
+        using C = Cfg<4, 2>;
+        if (device >= 0 && device < 64 && !once[device][2]) {
+            FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad3x3<4, 2>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+            once[device][2] = true;
+        }
+        const dim3 grid((unsigned)p.S, (unsigned)(Ci / C::BCIW), (unsigned)(p.Cor / C::BCO));
+        FOSVOS_PROF("k_wgrad3x3<4, 2>", st, flops);
+        hipLaunchKernelGGL((k_wgrad3x3<4, 2>), grid, dim3(C::NT), C::LDS_BYTES, st, a);
+    } else if (!p.side) {
         using C = Cfg<2, 2>;
         if (device >= 0 && device < 64 && !once[device][0]) {
             FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad3x3<2, 2>),
