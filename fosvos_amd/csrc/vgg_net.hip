@@ -280,11 +280,13 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
             FOSVOS_TRY(fosvos_maxpool2x2_ceil_bwd(act(kLastOfStage[s - 1]), reinterpret_cast<const uint16_t *>(base + a.gpooled[s - 1]),
                                                   gact(kLastOfStage[s - 1]), N, a.sh[s - 1], a.sw[s - 1], kStageCh[s - 1], 1,
                                                   device, sm));
-        if (buckets && s >= 3) {
-            // data-parallel step: the gradients of stage 5 (bucket 0) and stage 4 (bucket 1) - 87 % of the bytes - are
-            // finished and published here, so their all-reduce runs under the rest of the backward pass
+        if (s >= 1) {
+            // The slab reductions queued so far run now (two launches) instead of all at the end: the weight-gradient
+            // stream has slack, and what stands between the last data-gradient kernel and the optimizer step shrinks to
+            // stage 1's own reduction.  Data-parallel step: stage 5 (bucket 0) and stage 4 (bucket 1) - 87 % of the gradient
+            // bytes - are published here, so their all-reduce runs under the rest of the backward pass.
             FOSVOS_TRY(wgrad_reduce_all(&reduce, device, sa));
-            FOSVOS_HIP_CHECK(hipEventRecord(ev[kBucketEvent0 + (4 - s)], sa));
+            if (buckets && s >= 3) FOSVOS_HIP_CHECK(hipEventRecord(ev[kBucketEvent0 + (4 - s)], sa));
         }
     }
     FOSVOS_TRY(wgrad_reduce_all(&reduce, device, sa));  // slabs -> dw / db for all (remaining) layers

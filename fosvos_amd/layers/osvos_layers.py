@@ -2,6 +2,7 @@
 names, argument meaning and return values; the loss runs as one fused HIP kernel group.
 
   class_balanced_cross_entropy_loss  src/layers/osvos_layers.py:17-44  -> fosvos_cbce_loss
+  class_balanced_cross_entropy_loss_frames  (extension) the same loss per frame of a batch
   center_crop                        src/layers/osvos_layers.py:47-54  (index arithmetic only)
   upsample_filt / interp_surgery     src/layers/osvos_layers.py:57-81  (one-off host init)
   logit / sigmoid_np                 src/layers/osvos_layers.py:9-14   (numpy helpers)
@@ -65,6 +66,46 @@ def class_balanced_cross_entropy_loss(output, label, size_average=True, batch_co
         raise ValueError("class_balanced_cross_entropy_loss: output {} vs label {}".format(
             tuple(output.shape), tuple(label.shape)))
     return _CBCELoss.apply(output, label, size_average, batch_counts)
+
+
+class _CBCELossFrames(torch.autograd.Function):
+    """The loss of every frame of a batch on its own ([N,1,H,W] -> [N]): N launches of the fused loss kernel, gradients
+    in one buffer so that backward is a single scale."""
+
+    @staticmethod
+    def forward(ctx, output, label, size_average):
+        output, label = output.contiguous().float(), label.contiguous().float()
+        n = output.shape[0]
+        losses, grads = [], []
+        for i in range(n):
+            loss, grad = ops.cbce_loss(output[i:i + 1], label[i:i + 1], size_average=bool(size_average),
+                                       want_grad=output.requires_grad)
+            losses.append(loss)
+            grads.append(grad)
+        ctx.grad = torch.cat(grads) if grads[0] is not None else None
+        return torch.stack(losses)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.grad is None:
+            return None, None, None
+        return ctx.grad * g.reshape(-1, 1, 1, 1), None, None
+
+
+def class_balanced_cross_entropy_loss_frames(output, label, size_average=True):
+    """``class_balanced_cross_entropy_loss`` of each frame of a batch separately: a [N] tensor whose element i equals
+    ``class_balanced_cross_entropy_loss(output[i:i+1], label[i:i+1], size_average)``.  Not in the reference; the
+    online loop uses it when it runs several micro-batches of an accumulation cycle as one batched pass, where every
+    frame must keep the class weights of its own [1,1,H,W] tensor (src/train_online.py:80 calls the loss per frame)."""
+    if not output.is_cuda:
+        raise RuntimeError("class_balanced_cross_entropy_loss_frames: the HIP implementation needs GPU tensors "
+                           "(no CPU fallback)")
+    if label.device != output.device:
+        label = label.to(output.device)
+    if tuple(label.shape) != tuple(output.shape):
+        raise ValueError("class_balanced_cross_entropy_loss_frames: output {} vs label {}".format(
+            tuple(output.shape), tuple(label.shape)))
+    return _CBCELossFrames.apply(output, label, size_average)
 
 
 def crop_offsets(size, target):

@@ -20,7 +20,7 @@ import torch
 from torch import optim
 
 from config.mypath import Path as P
-from layers.osvos_layers import class_balanced_cross_entropy_loss
+from layers.osvos_layers import class_balanced_cross_entropy_loss, class_balanced_cross_entropy_loss_frames
 from util import gpu_handler, io_helper, experiment_helper, args_helper
 from util.logger import get_logger
 from util.network_provider import NetworkProvider, provider_mapping
@@ -28,6 +28,7 @@ from util.settings import OnlineSettings
 import parallel
 
 log = get_logger(__file__)
+_hip_cbce = class_balanced_cross_entropy_loss  # tests may rebind the module-level name to a CPU stand-in
 
 # run-wide locations; the reference keeps these as module globals set in __main__
 save_dir_models = Path('models')
@@ -67,6 +68,25 @@ def train_and_test(net_provider: NetworkProvider, seq_name: str, settings: Onlin
                         str(settings.variant_online))
         experiment_helper.test(net_provider, data_loader, save_dir, settings.is_visualizing_results,
                                settings.eval_speeds, seq_name=seq_name)
+
+
+def _max_group() -> int:
+    """Micro-batches of one accumulation cycle that may run as one batched pass (FOSVOS_MICROBATCH_GROUP, default 3;
+    1 = the reference's one-by-one order).  Not the whole cycle: the weight-gradient stream trails the data-gradient
+    chain, and what it still owes when the cycle's last backward pass ends stands in front of the optimizer step - with
+    two groups per cycle the first one's tail hides under the second one's forward pass."""
+    try:
+        return max(1, int(os.environ.get('FOSVOS_MICROBATCH_GROUP', '3')))
+    except ValueError:
+        return 3
+
+
+def _losses_per_frame(fused, gts):
+    """[k] per-frame losses of a batched pass; one fused op on the GPU, the reference's function per slice elsewhere."""
+    if fused.is_cuda and class_balanced_cross_entropy_loss is _hip_cbce:
+        return class_balanced_cross_entropy_loss_frames(fused, gts, size_average=False)
+    return torch.stack([class_balanced_cross_entropy_loss(fused[i:i + 1], gts[i:i + 1], size_average=False)
+                        for i in range(fused.shape[0])])
 
 
 class _Landed:
@@ -123,55 +143,105 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             log.info('Loss {0}: {1}'.format(seq_name, value))
             summary_writer.add_scalar('data/total_loss_epoch', value, ep)
 
+    def log_point(epoch: int, minibatch_index: int) -> None:
+        # the reference reads the running loss here (a device->host sync that drains the launch queue 20 times
+        # per run); the value is copied to pinned memory asynchronously instead and logged once it has landed
+        if device.type == 'cuda':
+            host_val = torch.empty((), dtype=torch.float32, pin_memory=True)
+            host_val.copy_(running_loss_tr, non_blocking=True)
+            landed = torch.cuda.Event()
+            landed.record()
+        else:  # CPU tensors (the gloo tests of the data-parallel wiring): nothing to wait for
+            host_val, landed = running_loss_tr.clone(), _Landed()
+        pending_logs.append((epoch, minibatch_index, host_val, landed))
+        running_loss_tr.zero_()
+        flush_logs(False)
+
+    def is_log_epoch(epoch: int) -> bool:
+        return epoch % log_every == log_every - 1
+
+    def is_snapshot_epoch(epoch: int) -> bool:
+        return (epoch % snapshot_every_n) == snapshot_every_n - 1
+
+    def run_group(group) -> None:
+        """One forward / loss / backward pass over the micro-batches of `group` (consecutive iterations of the reference's
+        loop, same frame size, inside one accumulation cycle).  The weights do not change inside a cycle, so running k
+        iterations as one batch of k frames leaves every frame's logits, loss (the class weights are still counted per
+        frame) and gradient contribution what the one-by-one loop computes; only the order of the fp32 sums over frames
+        differs.  What it buys on the GPU: k frames per kernel launch (the small stage-5 layers fill the chip without
+        split-K, fewer launch gaps) and one set of weight-gradient partial slabs per group instead of per frame."""
+        nonlocal counter_gradient, n_iters
+        k = len(group)
+        if k == 1:
+            inputs, gts = group[0][2]['image'], group[0][2]['gt']
+        else:
+            inputs = torch.cat([g[2]['image'] for g in group])
+            gts = torch.cat([g[2]['gt'] for g in group])
+        inputs, gts = gpu_handler.cast_cuda_if_possible([inputs, gts])
+
+        outputs = net.forward(inputs)
+
+        if k == 1:
+            loss = class_balanced_cross_entropy_loss(outputs[-1], gts, size_average=False)
+            losses = loss.detach().reshape(1)
+        else:
+            losses_k = _losses_per_frame(outputs[-1], gts)
+            loss = losses_k.sum()
+            losses = losses_k.detach()
+        if any(is_log_epoch(g[0]) for g in group):
+            for i, (epoch, minibatch_index, _mb, _end) in enumerate(group):
+                running_loss_tr.add_(losses[i])
+                if is_log_epoch(epoch):
+                    log_point(epoch, minibatch_index)
+        else:
+            running_loss_tr.add_(losses.sum() if k > 1 else losses[0])
+
+        # reference: `loss /= nAveGrad; loss.backward()` (src/train_online.py:92-93).  Seeding the backward pass with
+        # 1/nAveGrad is the same gradient (the division's own backward produces exactly this factor) without the
+        # three tiny kernels of the division, the ones-fill and its backward on the critical path
+        last_of_cycle = world > 1 and (counter_gradient + k) % local_accum == 0
+        if last_of_cycle:
+            sync.arm()
+        loss.backward(inv_avg)
+        if last_of_cycle:
+            sync.begin()
+        # (the reference also sums loss.item() into a per-epoch tensorboard scalar, src/train_online.py:94-104: one
+        # device sync per frame; running_loss_tr above carries the same information without it)
+        counter_gradient += k
+        n_iters += k
+
+        if counter_gradient % local_accum == 0:
+            net.join_gradients()
+            sync.finish()  # the bucketed all-reduce begun right behind the cycle's last backward pass
+            optimizer.step()
+            flat.zero()
+            counter_gradient = 0
+
+        epoch, _idx, _mb, end_of_epoch = group[-1]
+        if end_of_epoch and is_snapshot_epoch(epoch) and parallel.rank() == 0:
+            net_provider.save_model(epoch, sequence=seq_name)
+
     time_all_start = timeit.default_timer()
     n_iters = 0
+    max_group = _max_group()
+    group = []  # pending (epoch, minibatch index, minibatch, last of its epoch) tuples
     for epoch in range(start_epoch, n_epochs):
+        n_mb = len(dataloader)
         for minibatch_index, minibatch in enumerate(dataloader):
-            inputs, gts = minibatch['image'], minibatch['gt']
-            inputs, gts = gpu_handler.cast_cuda_if_possible([inputs, gts])
-
-            outputs = net.forward(inputs)
-
-            loss = class_balanced_cross_entropy_loss(outputs[-1], gts, size_average=False)
-            running_loss_tr += loss.detach()
-
-            if epoch % log_every == log_every - 1:
-                # the reference reads the running loss here (a device->host sync that drains the launch queue 20 times
-                # per run); the value is copied to pinned memory asynchronously instead and logged once it has landed
-                if device.type == 'cuda':
-                    host_val = torch.empty((), dtype=torch.float32, pin_memory=True)
-                    host_val.copy_(running_loss_tr, non_blocking=True)
-                    landed = torch.cuda.Event()
-                    landed.record()
-                else:  # CPU tensors (the gloo tests of the data-parallel wiring): nothing to wait for
-                    host_val, landed = running_loss_tr.clone(), _Landed()
-                pending_logs.append((epoch, minibatch_index, host_val, landed))
-                running_loss_tr.zero_()
-                flush_logs(False)
-
-            # reference: `loss /= nAveGrad; loss.backward()` (src/train_online.py:92-93).  Seeding the backward pass with
-            # 1/nAveGrad is the same gradient (the division's own backward produces exactly this factor) without the
-            # three tiny kernels of the division, the ones-fill and its backward on the critical path
-            last_of_cycle = world > 1 and (counter_gradient + 1) % local_accum == 0
-            if last_of_cycle:
-                sync.arm()
-            loss.backward(inv_avg)
-            if last_of_cycle:
-                sync.begin()
-            # (the reference also sums loss.item() into a per-epoch tensorboard scalar, src/train_online.py:94-104: one
-            # device sync per frame; running_loss_tr above carries the same information without it)
-            counter_gradient += 1
-            n_iters += 1
-
-            if counter_gradient % local_accum == 0:
-                net.join_gradients()
-                sync.finish()  # the bucketed all-reduce begun right behind the cycle's last backward pass
-                optimizer.step()
-                flat.zero()
-                counter_gradient = 0
-
-        if (epoch % snapshot_every_n) == snapshot_every_n - 1 and parallel.rank() == 0:
-            net_provider.save_model(epoch, sequence=seq_name)
+            shape = tuple(minibatch['image'].shape)
+            if group and (tuple(group[-1][2]['image'].shape) != shape or shape[0] != 1):
+                run_group(group)
+                group = []
+            end_of_epoch = minibatch_index == n_mb - 1
+            group.append((epoch, minibatch_index, minibatch, end_of_epoch))
+            full = len(group) >= max_group or (counter_gradient + len(group)) % local_accum == 0
+            # a group ends with its accumulation cycle, and before a snapshot is due (the snapshot must hold exactly the
+            # updates up to its epoch)
+            if full or shape[0] != 1 or (end_of_epoch and is_snapshot_epoch(epoch)):
+                run_group(group)
+                group = []
+    if group:
+        run_group(group)
 
     net.defer_wgrad_join = False  # joins
     net.compute_side_outputs = True

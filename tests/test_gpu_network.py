@@ -268,6 +268,59 @@ def test_shipped_online_train_vs_golden(golden, tag, lr):
     assert all(tuple(o.shape) == (1, 1, 48, 86) for o in outs)
 
 
+def test_grouped_micro_batches_equal_one_by_one(monkeypatch):
+    """`train_online._train` runs up to FOSVOS_MICROBATCH_GROUP micro-batches of an accumulation cycle as one batched
+    pass.  Against the reference's one-by-one order (group size 1) on the same seven same-size frames, avg_grad_every_n = 5.
+    A frame's logits do not depend on its batch mates, but the kernels pick tiles / K splits by the pixel count of the
+    launch, so fp32 sums inside a conv may run in another order and bf16 roundings flip: per-frame losses agree to the
+    forward tolerance, the applied weight deltas to the gradient tolerance, frozen tensors untouched."""
+    import train_online
+    from util.network_provider import VGGOnlineProvider
+    frames = [O.synthetic_frame(1, 40, 70, seed=70 + i) for i in range(7)]
+    loader = [{"image": x, "gt": gt} for x, gt in frames]
+    # a batched pass is the per-frame pass, frame by frame
+    net, _ = make_net(17)
+    xb = torch.cat([x for x, _ in frames[:3]]).to(DEV)
+    with torch.no_grad():
+        batched = net(xb)[-1]
+        for i in range(3):
+            single = net(xb[i:i + 1])[-1]
+            assert (batched[i:i + 1] - single).abs().max().item() <= 5e-3 * single.abs().max().item()
+    runs = {}
+    for group in (1, 3, 5):
+        monkeypatch.setenv("FOSVOS_MICROBATCH_GROUP", str(group))
+        net, sd = make_net(17)
+        prov = VGGOnlineProvider.__new__(VGGOnlineProvider)
+        prov.network = net
+        prov.name = "vgg16"
+        opt = prov.get_optimizer(learning_rate=1e-9)
+        train_online.data_parallel = False
+        ret = train_online._train(prov, loader, opt, _NullWriter(), "grouped", 0, 2, 5, 10 ** 9)  # 14 iterations, 2 steps
+        assert ret["iterations"] == 14
+        runs[group] = (ret["loss"], {n_: p.detach().clone() for n_, p in net.named_parameters()}, sd)
+    base_loss, base_w, sd = runs[1]
+    assert len(base_loss) == 14  # with 2 epochs every iteration is a logging point (src/train_online.py:84)
+    for group in (3, 5):
+        loss, w, _ = runs[group]
+        np.testing.assert_allclose(loss, base_loss, rtol=2e-2)
+        moved, ratios = 0, []
+        for n_ in base_w:
+            d_ref = (base_w[n_] - sd[n_].to(DEV)).double().reshape(-1)
+            d_got = (w[n_] - sd[n_].to(DEV)).double().reshape(-1)
+            if n_.startswith(("upscale", "score_dsn")):
+                assert float(d_got.abs().max()) == 0.0
+                continue
+            if float(d_ref.abs().max()) == 0.0:
+                continue
+            ulp = float(np.spacing(np.float32(max(sd[n_].abs().max().item(), 1e-30))))
+            noise = 2 * ulp * float(np.sqrt(d_ref.numel()))
+            ratios.append(max(float((d_got - d_ref).norm()) - noise, 0.0) / float(d_ref.norm()))
+            assert ratios[-1] <= GRAD_REL_L2, (group, n_, ratios[-1])
+            moved += 1
+        assert moved >= 30
+        print(f"[group {group}] worst delta rel-L2 vs one-by-one {max(ratios):.3e}")
+
+
 def test_shipped_offline_train_vs_golden(golden):
     """`train_offline._train` ITSELF on the golden's schedule (4 iterations of epoch 60 of 240, step every 2, five
     deeply supervised losses, src/train_offline.py:77-110): the five loss values of the epoch and the applied weight
