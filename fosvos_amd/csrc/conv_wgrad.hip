@@ -426,10 +426,10 @@ int target_blocks() {  // FOSVOS_WGRAD_BLOCKS: lab switch, read once
     static const int v = [] {
         const char *e = getenv("FOSVOS_WGRAD_BLOCKS");
         const int n = e ? atoi(e) : 0;
-        // 128: the weight-gradient kernels run BESIDE the data-gradient chain (vgg_net.hip) and a CU that hosts one of these
-        // workgroups has room for one igemm workgroup instead of two; alone on the chip 256 is faster (47 vs 66 us at
-        // conv1_2), in the step 128 wins (738 vs 713 frames/s) and halves the slab bytes
-        return n > 0 ? n : 128;
+        // The weight-gradient kernels run BESIDE the data-gradient chain (vgg_net.hip), and a CU that hosts one of these
+        // workgroups has room for one igemm workgroup instead of two; slab bytes grow with the workgroup count.  Measured on
+        // the fine-tune step with three frames per pass: 128 -> 927, 192 -> 952, 256 -> 945 frames/s
+        return n > 0 ? n : 192;
     }();
     return v;
 }

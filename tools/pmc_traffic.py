@@ -34,8 +34,9 @@ for n in sorted(set(fetch) | set(write)):
     wb = write.get(n, [0, 0.0])[1] * 1024.0
     rows[n] = {"launches": calls, "launches_per_step": calls / steps, "hbm_read_bytes_per_launch": fb / calls,
                "hbm_write_bytes_per_launch": wb / calls, "hbm_bytes_per_step": (fb + wb) / steps}
-fam = {"igemm": [k for k in rows if "k_conv3x3_igemm" in k], "wgrad": [k for k in rows if k.startswith("void k_wgrad<")],
-       "wgrad_reduce": [k for k in rows if "k_wgrad_f" in k]}
+fam = {"igemm": [k for k in rows if "k_conv3x3_igemm" in k],
+       "wgrad": [k for k in rows if "k_wgrad3x3" in k or "k_wgrad_first" in k],
+       "wgrad_reduce": [k for k in rows if "k_wgrad_fold" in k or "k_wgrad_reduce" in k]}
 summary = {}
 for name, ks in fam.items():
     launches = sum(rows[k]["launches"] for k in ks)
@@ -51,7 +52,7 @@ summary["conv_mfma_family"]["hbm_bytes_per_launch"] = (summary["conv_mfma_family
                                                        summary["conv_mfma_family"]["launches_per_step"])
 summary["all_kernels_hbm_bytes_per_step"] = sum(r["hbm_bytes_per_step"] for r in rows.values())
 json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py "
-                     "--steps 10 --warmup 5 --no-cpu-baseline --no-roofline",
+                     "--steps 10 --warmup 5 --no-cpu-baseline --no-roofline --no-infer",
            "corrections": "bytes = KiB * 1024; FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B)",
            "steps_profiled": steps, "summary": summary, "per_kernel": rows}, open(out, "w"), indent=1)
 for k, v in summary.items():
