@@ -62,7 +62,7 @@ struct WgradReduceEntry {
     float *dw, *db;          // db may be null
     const float *bias_part;  // [S][Cor]
     int64_t E_real, E_pad;
-    int S, Co, Cor, accumulate;
+    int S, S_bias, Co, Cor, accumulate;  // S slabs, S_bias bias partials per channel
     int block_begin, n_blocks;  // block range inside the batched final launch (n_blocks cover the layer's elements once)
     int fold_begin, fold_blocks;  // ... inside the batched fold launch (0 blocks: no fold stage, S <= 8)
 };
@@ -79,7 +79,7 @@ int first_wgrad_impl(const float *frame, const uint16_t *dy, float *dw, float *d
                      WgradReduceTable *reduce);
 int wgrad_reduce_all(WgradReduceTable *reduce, int device, void *stream);
 // queue (or, reduce == nullptr, run) the sum over S slabs of E_pad floats each into dw's E_real floats and db's Co
-int wgrad_queue_reduce(const float *slabs, const float *bias_part, float *dw, float *db, int S, int64_t E_real,
+int wgrad_queue_reduce(const float *slabs, const float *bias_part, float *dw, float *db, int S, int S_bias, int64_t E_real,
                        int64_t E_pad, int Co, int Cor, int accumulate, WgradReduceTable *reduce, int device, void *stream);
 // Head backward in pieces, so that vgg_net.hip can put the scales the data-gradient chain does not need yet on the
 // auxiliary stream: check once, then one call per scale (any order, any stream) and the finish pass (after all four).

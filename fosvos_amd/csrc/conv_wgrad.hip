@@ -38,7 +38,7 @@ struct WgArgs {
     const uint16_t *x;   // [N,H,W,Ci]
     const uint16_t *dy;  // [N,H,W,Cy]  (Cy = roundup(Co,32))
     float *slabs;        // [S][Cor][Ci][9]
-    float *bias_part;    // [S][Cor] per-split column sums of dy, or null
+    float *bias_part;    // [S * gridDim.y][Cor] column sums of dy per split and ci block (each sums its share of the tiles), or null
     int N, H, W, Ci, Cy, Cor;
     int tiles_x, tiles_y, n_tiles, tiles_per_split;
 #ifdef FOSVOS_WG_STAMP
@@ -58,9 +58,6 @@ __device__ __forceinline__ bf16x8 tr_pair(const char *p) {
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
-
-// 16 zero bytes every out-of-image piece is loaded from instead (unconditional loads, no branch around a load)
-__device__ uint4 g_zero16_w;
 
 #ifdef FOSVOS_WG_STAMP
 unsigned long long *g_wg_stamps = nullptr;
@@ -127,31 +124,43 @@ __global__ __launch_bounds__(64 * WCO * WCI) __attribute__((amdgpu_waves_per_eu(
     const int rd_y = wc * C::Y_HALF + lane_off;                 // + row * 16 * 64
     const int rd_x = C::Y_BYTES + wi * C::X_HALF + lane_off;    // + (R * 18 + kx) * 64
 
-    const bool do_bias = a.bias_part != nullptr && blockIdx.y == 0;
+    // the bias gradient (column sums of dy) is the same for every ci block of a split: the ci blocks share it out by tile, so
+    // no workgroup carries all of it (all workgroups of a launch end together: the slowest sets the kernel time)
+    const bool do_bias = a.bias_part != nullptr;
     float bsum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
     // ---- tile-independent staging plan of this thread: piece i = it * 256 + tid -> (pixel, 16-byte chunk)
-    int y_goff[C::Y_IT], y_lds[C::Y_IT], y_rc[C::Y_IT];
+    // y_goff / x_goff: BYTE offsets inside the tile, from the tile's dy origin / from the x halo origin (one row and one
+    // pixel in front of the tile).  The loads are buffer loads: descriptor + this 32-bit offset + a scalar tile offset, and
+    // an out-of-image piece gets the offset ~0, which the descriptor's range check answers with zeros (no zero page, no
+    // 64-bit address arithmetic per piece)
+    unsigned y_goff[C::Y_IT], x_goff[C::X_IT];
+    int y_lds[C::Y_IT], y_rc[C::Y_IT];
 #pragma unroll
     for (int it = 0; it < C::Y_IT; ++it) {
         const int i = it * C::NT + tid, pix = i / C::CHY, c = i % C::CHY;
         const int ty = pix >> 4, tx = pix & 15;
         y_rc[it] = (ty << 16) | tx;
-        y_goff[it] = (ty * W + tx) * a.Cy + co0 + c * 8;
+        y_goff[it] = (unsigned)(((ty * W + tx) * a.Cy + co0 + c * 8) * 2);
         y_lds[it] = (c >> 2) * C::Y_HALF + pix * 64 + (c & 3) * 16;
     }
-    int x_goff[C::X_IT], x_lds[C::X_IT], x_rc[C::X_IT];
+    int x_lds[C::X_IT], x_rc[C::X_IT];
 #pragma unroll
     for (int it = 0; it < C::X_IT; ++it) {
         const int i = it * C::NT + tid, pix = i / C::CHX, c = i % C::CHX;
         const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
         x_rc[it] = pix < NPH ? ((hy << 16) | hx) : (0x7fff << 16);  // slots past the halo: never in the image, never stored
-        x_goff[it] = ((hy - 1) * W + (hx - 1)) * a.Ci + ci0 + c * 8;
+        x_goff[it] = pix < NPH ? (unsigned)(((hy * W + hx) * a.Ci + ci0 + c * 8) * 2) : ~0u;  // slots past the halo: zeros
         x_lds[it] = C::Y_BYTES + (c >> 2) * C::X_HALF + pix * 64 + (c & 3) * 16;
     }
-    const void *zero = &g_zero16_w;
+    // x descriptor: based one row and one pixel in FRONT of the tensor, so that halo offsets are non-negative (the bytes in
+    // front of the tensor belong to out-of-image halo pieces, which are never requested)
+    const int64_t halo_shift = (int64_t)(W + 1) * a.Ci;
+    const unsigned y_total = (unsigned)((int64_t)a.N * H * W * a.Cy * 2), x_total = (unsigned)(((int64_t)a.N * H * W * a.Ci + halo_shift) * 2);
+    const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.dy), 0, y_total, 0x00020000);
+    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.x) - halo_shift, 0, x_total, 0x00020000);
 
     const int t_begin = split * a.tiles_per_split;
     const int t_end = min(t_begin + a.tiles_per_split, a.n_tiles);
@@ -167,22 +176,27 @@ __global__ __launch_bounds__(64 * WCO * WCI) __attribute__((amdgpu_waves_per_eu(
     py0 = py1 = py2 = py3 = px0 = px1 = px2 = px3 = px4 = px5 = px6 = px7 = px8 = px9 = px10 = px11 = make_uint4(0, 0, 0, 0);
 #define FOSVOS_WG_LDY(i_)                                                                               \
     if constexpr ((i_) < C::Y_IT) {                                                                     \
-        const bool ok_ = (y_rc[i_] >> 16) < vrows_ && (y_rc[i_] & 0xffff) < vcols_ && live_;             \
-        py##i_ = *reinterpret_cast<const uint4 *>(ok_ ? (const void *)(ybase_ + y_goff[i_]) : zero);    \
+        unsigned v_ = y_goff[i_];                                                                       \
+        if (!interior_) v_ = ((y_rc[i_] >> 16) < vrows_ && (y_rc[i_] & 0xffff) < vcols_ && live_) ? v_ : ~0u; \
+        py##i_ = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, v_, ysoff_, 0)); \
     }
 #define FOSVOS_WG_LDX(i_)                                                                               \
     if constexpr ((i_) < C::X_IT) {                                                                     \
-        const int hy_ = x_rc[i_] >> 16, hx_ = x_rc[i_] & 0xffff;                                        \
-        const bool ok_ = hy_ >= 1 - y0_ && hy_ <= vrows_ && hx_ >= 1 - x0_ && hx_ <= vcols_ && live_;     \
-        px##i_ = *reinterpret_cast<const uint4 *>(ok_ ? (const void *)(xbase_ + x_goff[i_]) : zero);    \
+        unsigned v_ = x_goff[i_];                                                                       \
+        if (!interior_) {                                                                               \
+            const int hy_ = x_rc[i_] >> 16, hx_ = x_rc[i_] & 0xffff;                                    \
+            v_ = (hy_ >= 1 - y0_ && hy_ <= vrows_ && hx_ >= 1 - x0_ && hx_ <= vcols_ && live_) ? v_ : ~0u; \
+        }                                                                                               \
+        px##i_ = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, v_, xsoff_, 0)); \
     }
     // tile-level scalars of the tile the NEXT loads fetch: (lt_x, lt_y, lt_n)
 #define FOSVOS_WG_TILE_SCALARS()                                                                        \
     const int y0_ = lt_y * TH, x0_ = lt_x * 16;                                                         \
     const int vrows_ = H - y0_, vcols_ = W - x0_;                                                       \
     const int64_t org_ = ((int64_t)lt_n * H + y0_) * W + x0_;                                           \
-    const uint16_t *ybase_ = a.dy + org_ * a.Cy;                                                        \
-    const uint16_t *xbase_ = a.x + org_ * a.Ci;
+    const unsigned ysoff_ = (unsigned)(org_ * a.Cy * 2), xsoff_ = (unsigned)(org_ * a.Ci * 2);          \
+    /* interior: the whole halo lies inside the image and the loads are wanted - no per-piece checks */ \
+    const bool interior_ = y0_ >= 1 && y0_ + TH < H && x0_ >= 1 && x0_ + 16 < W && live_;
 #define FOSVOS_WG_ADVANCE()                                                                             \
     if (++lt_x == a.tiles_x) {                                                                          \
         lt_x = 0;                                                                                       \
@@ -241,7 +255,7 @@ __global__ __launch_bounds__(64 * WCO * WCI) __attribute__((amdgpu_waves_per_eu(
         const bool live_ = has_next && !(a.lab & 2);
         FOSVOS_WG_TILE_SCALARS()
         FOSVOS_WG_STAMP_AT(1)
-        if (!FOSVOS_WG_BIAS_IN_ROWS && do_bias) {  // column sums of the dy tile: thread t keeps chunk t % CHY (8 channels)
+        if (!FOSVOS_WG_BIAS_IN_ROWS && do_bias && (tile % (int)gridDim.y) == (int)blockIdx.y) {  // thread t keeps chunk t % CHY
 #pragma unroll
             for (int k = 0; k < C::Y_IT; ++k) {
                 float f[8];
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(64 * WCO * WCI) __attribute__((amdgpu_waves_per_eu(
             const int c = tid >> 3, e = tid & 7;
             float acc_b = 0.f;
             for (int t2 = c; t2 < C::NT; t2 += C::CHY) acc_b += sb[t2 * 9 + e];
-            a.bias_part[(int64_t)split * a.Cor + co0 + tid] = acc_b;
+            a.bias_part[((int64_t)split * gridDim.y + blockIdx.y) * a.Cor + co0 + tid] = acc_b;
         }
     }
     // ---- slab write, laid out like dw (OIHW): accumulator register r of lane l is
@@ -409,13 +423,13 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradReduceTable t) 
         // 16 partials in flight per thread (a rolled loop paid one L2 round trip per split: 65 us at 250 splits)
         for (int co = threadIdx.x; co < q.Co; co += 256) {
             float acc_b = 0.f;
-            for (int s0 = 0; s0 < q.S; s0 += 16) {
+            for (int s0 = 0; s0 < q.S_bias; s0 += 16) {
                 float v[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = q.bias_part[(int64_t)min(s0 + j, q.S - 1) * q.Cor + co];
+                for (int j = 0; j < 16; ++j) v[j] = q.bias_part[(int64_t)min(s0 + j, q.S_bias - 1) * q.Cor + co];
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
-                    if (s0 + j < q.S) acc_b += v[j];
+                    if (s0 + j < q.S_bias) acc_b += v[j];
             }
             q.db[co] = q.accumulate ? q.db[co] + acc_b : acc_b;
         }
@@ -443,7 +457,7 @@ int wgrad_waves() {  // FOSVOS_WGRAD_WAVES=8: 128 co x 64 ci eight-wave workgrou
 }
 
 struct Plan {
-    int Cor, Cy, side, wide, tiles_x, tiles_y, n_tiles, tps, S;
+    int Cor, Cy, side, wide, tiles_x, tiles_y, n_tiles, tps, S, n_ci;
     size_t slab_bytes, bias_bytes;
 };
 
@@ -466,7 +480,8 @@ Plan make_plan(int N, int H, int W, int Ci, int Co) {
     p.tps = (int)cdiv(p.n_tiles, S);
     p.S = (int)cdiv(p.n_tiles, p.tps);
     p.slab_bytes = (size_t)p.S * 9 * p.Cor * Ci * sizeof(float);
-    p.bias_bytes = (size_t)p.S * p.Cor * sizeof(float);
+    p.n_ci = p.side ? Ci / 128 : Ci / 64;  // ci blocks (gridDim.y) share the bias sums of a split
+    p.bias_bytes = (size_t)p.S * p.n_ci * p.Cor * sizeof(float);
     return p;
 }
 
@@ -475,16 +490,17 @@ int check_shape(int N, int H, int W, int Ci, int Co, const char *who) {
     FOSVOS_REQUIRE(Ci % BCI == 0, FOSVOS_E_SHAPE, "%s: Ci=%d must be a multiple of %d", who, Ci, BCI);
     FOSVOS_REQUIRE(Co % 64 == 0 || (Co == 16 && Ci % 128 == 0), FOSVOS_E_SHAPE,
                    "%s: Co=%d must be a multiple of 64, or 16 with Ci a multiple of 128", who, Co);
-    FOSVOS_REQUIRE((int64_t)H * W * std::max(Ci, roundup(Co, 32)) < 0x7fffffffLL, FOSVOS_E_SHAPE,
-                   "%s: one image exceeds 2^31 elements", who);
+    FOSVOS_REQUIRE(((int64_t)N * H * W + W + 1) * std::max(Ci, roundup(Co, 32)) * 2 < 0xffffffffLL, FOSVOS_E_SHAPE,
+                   "%s: a tensor of %d x %d x %d x %d bf16 exceeds the 4 GB a buffer descriptor addresses", who, N, H, W,
+                   std::max(Ci, roundup(Co, 32)));
     return FOSVOS_OK;
 }
 
 // Queue the reduction of the layer whose slabs the MFMA kernel just wrote, or (reduce == nullptr) run it now.
 int finish_or_queue(const Plan &p, float *slabs, float *bias_part, float *dw, float *db, int Ci, int Co, int accumulate,
                     WgradReduceTable *reduce, int device, hipStream_t st) {
-    return fosvos::wgrad_queue_reduce(slabs, bias_part, dw, db, p.S, 9LL * Co * Ci, 9LL * p.Cor * Ci, Co, p.Cor, accumulate,
-                                      reduce, device, st);
+    return fosvos::wgrad_queue_reduce(slabs, bias_part, dw, db, p.S, p.S * p.n_ci, 9LL * Co * Ci, 9LL * p.Cor * Ci, Co, p.Cor,
+                                      accumulate, reduce, device, st);
 }
 }  // namespace
 
@@ -524,7 +540,8 @@ extern "C" int fosvos_conv3x3_wgrad_slabs(const uint16_t *x, const uint16_t *dy,
                               device, stream, &sink);
 }
 
-int fosvos::wgrad_queue_reduce(const float *slabs, const float *bias_part, float *dw, float *db, int S, int64_t E_real,
+int fosvos::wgrad_queue_reduce(const float *slabs, const float *bias_part, float *dw, float *db, int S, int S_bias,
+                               int64_t E_real,
                                int64_t E_pad, int Co, int Cor, int accumulate, WgradReduceTable *reduce, int device,
                                void *stream) {
     WgradReduceTable local;
@@ -534,7 +551,7 @@ int fosvos::wgrad_queue_reduce(const float *slabs, const float *bias_part, float
     FOSVOS_REQUIRE(E_real % 4 == 0 && E_pad % 4 == 0, FOSVOS_E_SHAPE, "wgrad: slab size must be a multiple of 4 floats");
     WgradReduceEntry &q = t->e[t->n];
     q.slabs = slabs; q.dw = dw; q.db = db; q.bias_part = db ? bias_part : nullptr;
-    q.S = S; q.Co = Co; q.Cor = Cor; q.accumulate = accumulate;
+    q.S = S; q.S_bias = S_bias; q.Co = Co; q.Cor = Cor; q.accumulate = accumulate;
     q.E_real = E_real;
     q.E_pad = E_pad;
     q.n_blocks = (int)cdiv(E_real / 4, 256);

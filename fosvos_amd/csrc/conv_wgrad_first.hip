@@ -260,6 +260,6 @@ int fosvos::first_wgrad_impl(const float *frame, const uint16_t *dy, float *dw, 
     FOSVOS_PROF("k_wgrad_first", st, 2.0 * N * H * W * 27.0 * CO);
     hipLaunchKernelGGL(k_wgrad_first, dim3((unsigned)p.S), dim3(256), LDS_BYTES, st, a);
     FOSVOS_LAUNCH_CHECK();
-    return fosvos::wgrad_queue_reduce(a.slabs, a.bias_part, dw, db, p.S, (int64_t)CO * NTAP, (int64_t)CO * NTAP, CO, CO,
+    return fosvos::wgrad_queue_reduce(a.slabs, a.bias_part, dw, db, p.S, p.S, (int64_t)CO * NTAP, (int64_t)CO * NTAP, CO, CO,
                                       accumulate, reduce, device, stream);
 }
