@@ -73,7 +73,7 @@ struct WgradReduceTable {
 };
 int wgrad_impl(const uint16_t *x, const uint16_t *dy, float *dw, float *db, int N, int H, int W, int Ci, int Co,
                int accumulate, void *workspace, size_t workspace_bytes, int device, void *stream,
-               WgradReduceTable *reduce);
+               WgradReduceTable *reduce, bool alone = false);
 int first_wgrad_impl(const float *frame, const uint16_t *dy, float *dw, float *db, int N, int H, int W, int Co,
                      int accumulate, void *workspace, size_t workspace_bytes, int device, void *stream,
                      WgradReduceTable *reduce);

@@ -461,7 +461,9 @@ struct Plan {
     size_t slab_bytes, bias_bytes;
 };
 
-Plan make_plan(int N, int H, int W, int Ci, int Co) {
+// alone: the launch will find the chip idle (the cycle's last backward pass has run out of data-gradient kernels by the
+// time stages 1-2 get their weight gradients): 256 workgroups, one per CU, instead of the shared-chip default
+Plan make_plan(int N, int H, int W, int Ci, int Co, bool alone = false) {
     Plan p;
     p.side = Co % 64 != 0;            // side_prep: 16 outputs in a 32-wide dy image, <1,4> workgroups
     p.Cor = p.side ? Co : roundup(Co, 64);  // slab / bias-partial rows: side_prep keeps its 16 real channels only
@@ -474,7 +476,7 @@ Plan make_plan(int N, int H, int W, int Ci, int Co) {
     // beside it lose more than the weight-gradient stream gains: 705 vs 738 frames/s on the fine-tune step
     p.wide = !p.side && Co % 128 == 0 && wgrad_waves() == 8;
     const int out_blocks = p.side ? Ci / 128 : (p.Cor / (p.wide ? 128 : 64)) * (Ci / 64);
-    int S = (int)cdiv(target_blocks(), out_blocks);
+    int S = (int)cdiv(alone ? std::max(256, target_blocks()) : target_blocks(), out_blocks);
     if (S > p.n_tiles) S = p.n_tiles;
     if (S < 1) S = 1;
     p.tps = (int)cdiv(p.n_tiles, S);
@@ -506,8 +508,8 @@ int finish_or_queue(const Plan &p, float *slabs, float *bias_part, float *dw, fl
 
 extern "C" size_t fosvos_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int Ci, int Co) {
     if (N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % BCI != 0) return 0;
-    const Plan p = make_plan(N, H, W, Ci, Co);
-    return p.slab_bytes + p.bias_bytes;
+    const Plan p = make_plan(N, H, W, Ci, Co), q = make_plan(N, H, W, Ci, Co, true);  // room for either split count
+    return std::max(p.slab_bytes + p.bias_bytes, q.slab_bytes + q.bias_bytes);
 }
 
 extern "C" int fosvos_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, float *dw, float *db, int N, int H, int W,
@@ -583,10 +585,10 @@ int fosvos::wgrad_reduce_all(WgradReduceTable *reduce, int device, void *stream)
 
 int fosvos::wgrad_impl(const uint16_t *x, const uint16_t *dy, float *dw, float *db, int N, int H, int W, int Ci, int Co,
                        int accumulate, void *workspace, size_t workspace_bytes, int device, void *stream,
-                       WgradReduceTable *reduce) {
+                       WgradReduceTable *reduce, bool alone) {
     FOSVOS_REQUIRE(x && dy && dw && workspace, FOSVOS_E_ARG, "conv3x3_wgrad: null pointer");
     if (int rc = check_shape(N, H, W, Ci, Co, "conv3x3_wgrad")) return rc;
-    const Plan p = make_plan(N, H, W, Ci, Co);
+    const Plan p = make_plan(N, H, W, Ci, Co, alone);
     FOSVOS_REQUIRE(workspace_bytes >= p.slab_bytes + p.bias_bytes, FOSVOS_E_WORKSPACE,
                    "conv3x3_wgrad: workspace %zu < %zu", workspace_bytes, p.slab_bytes + p.bias_bytes);
     FOSVOS_ENTER(device);

@@ -32,7 +32,10 @@ __device__ __forceinline__ void load4(const float *__restrict__ p, int64_t i, in
     }
 }
 
+// blockIdx.y = frame: every frame of a batch is its own loss (own class counts, own workspace record, own output)
 __global__ __launch_bounds__(kBlock) void k_count(const float *__restrict__ label, int64_t n, Ws *ws) {
+    label += (int64_t)blockIdx.y * n;
+    ws += blockIdx.y;
     unsigned cnt = 0;
     const int64_t stride = (int64_t)gridDim.x * kBlock * kPerThread;
     for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kPerThread; i < n; i += stride) {
@@ -54,6 +57,10 @@ __global__ __launch_bounds__(kBlock) void k_loss(const float *__restrict__ x, co
                                                   int64_t n, int size_average, float grad_scale,
                                                   float *__restrict__ grad, Ws *ws, int n_count_blocks,
                                                   const double *__restrict__ ext_counts) {
+    x += (int64_t)blockIdx.y * n;
+    label += (int64_t)blockIdx.y * n;
+    if (grad) grad += (int64_t)blockIdx.y * n;
+    ws += blockIdx.y;
     __shared__ double s_pos[kBlock / 64], s_neg[kBlock / 64];
     __shared__ unsigned long long s_np;
     if (!ext_counts) {   // integer sum of the per-block counts: order-independent, so every block agrees exactly
@@ -120,6 +127,8 @@ __global__ __launch_bounds__(kBlock) void k_loss(const float *__restrict__ x, co
 
 __global__ __launch_bounds__(64) void k_finish(int64_t n, int size_average, const Ws *ws, int n_blocks,
                                                 float *__restrict__ loss_out, const double *__restrict__ ext_counts) {
+    ws += blockIdx.x;
+    loss_out += blockIdx.x;
     // lane t sums entries t, t+64, ... then a fixed butterfly: the order never changes run to run
     unsigned long long np = 0;
     double pos = 0.0, neg = 0.0;
@@ -158,13 +167,17 @@ __global__ __launch_bounds__(64) void k_finish(int64_t n, int size_average, cons
 extern "C" size_t fosvos_cbce_workspace_bytes(int64_t) { return sizeof(Ws); }
 
 namespace {
-int cbce_impl(const float *logits, const float *label, int64_t numel, int size_average, float grad_scale,
+int cbce_impl(const float *logits, const float *label, int64_t numel, int n_frames, int size_average, float grad_scale,
               const double *batch_counts, float *loss_out, float *grad, void *workspace, size_t workspace_bytes,
               int device, void *stream) {
     FOSVOS_REQUIRE(logits && label && loss_out && workspace, FOSVOS_E_ARG, "cbce_loss: null pointer");
     FOSVOS_REQUIRE(numel > 0, FOSVOS_E_SHAPE, "cbce_loss: numel=%lld", (long long)numel);
-    FOSVOS_REQUIRE(workspace_bytes >= sizeof(Ws), FOSVOS_E_WORKSPACE, "cbce_loss: workspace %zu < %zu",
-                   workspace_bytes, sizeof(Ws));
+    FOSVOS_REQUIRE(n_frames >= 1 && n_frames <= 65535, FOSVOS_E_SHAPE, "cbce_loss: n_frames=%d", n_frames);
+    FOSVOS_REQUIRE(n_frames == 1 || numel % 4 == 0, FOSVOS_E_SHAPE,
+                   "cbce_loss_frames: %lld elements per frame - frames after the first would start off a 16-byte boundary",
+                   (long long)numel);
+    FOSVOS_REQUIRE(workspace_bytes >= n_frames * sizeof(Ws), FOSVOS_E_WORKSPACE, "cbce_loss: workspace %zu < %zu",
+                   workspace_bytes, n_frames * sizeof(Ws));
     FOSVOS_REQUIRE(((uintptr_t)logits % 16 == 0) && ((uintptr_t)label % 16 == 0) && (!grad || (uintptr_t)grad % 16 == 0),
                    FOSVOS_E_ARG, "cbce_loss: pointers must be 16-byte aligned");
     FOSVOS_ENTER(device);
@@ -174,15 +187,15 @@ int cbce_impl(const float *logits, const float *label, int64_t numel, int size_a
     hipStream_t s = (hipStream_t)stream;
     if (!batch_counts) {
         FOSVOS_PROF("k_count", s, 0.0);
-        hipLaunchKernelGGL(k_count, dim3(blocks), dim3(kBlock), 0, s, label, numel, ws);
+        hipLaunchKernelGGL(k_count, dim3(blocks, n_frames), dim3(kBlock), 0, s, label, numel, ws);
         FOSVOS_LAUNCH_CHECK();
     }
     FOSVOS_PROF("k_loss", s, 0.0);
-    hipLaunchKernelGGL(k_loss, dim3(blocks), dim3(kBlock), 0, s, logits, label, numel, size_average, grad_scale, grad,
+    hipLaunchKernelGGL(k_loss, dim3(blocks, n_frames), dim3(kBlock), 0, s, logits, label, numel, size_average, grad_scale, grad,
                        ws, blocks, batch_counts);
     FOSVOS_LAUNCH_CHECK();
     FOSVOS_PROF("k_finish", s, 0.0);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, s, numel, size_average, ws, blocks, loss_out, batch_counts);
+    hipLaunchKernelGGL(k_finish, dim3(n_frames), dim3(64), 0, s, numel, size_average, ws, blocks, loss_out, batch_counts);
     FOSVOS_LAUNCH_CHECK();
     return FOSVOS_OK;
 }
@@ -191,8 +204,15 @@ int cbce_impl(const float *logits, const float *label, int64_t numel, int size_a
 extern "C" int fosvos_cbce_loss(const float *logits, const float *label, int64_t numel, int size_average,
                                 float grad_scale, float *loss_out, float *grad, void *workspace,
                                 size_t workspace_bytes, int device, void *stream) {
-    return cbce_impl(logits, label, numel, size_average, grad_scale, nullptr, loss_out, grad, workspace, workspace_bytes,
+    return cbce_impl(logits, label, numel, 1, size_average, grad_scale, nullptr, loss_out, grad, workspace, workspace_bytes,
                      device, stream);
+}
+
+extern "C" int fosvos_cbce_loss_frames(const float *logits, const float *label, int64_t frame_numel, int n_frames,
+                                       int size_average, float grad_scale, float *loss_out, float *grad, void *workspace,
+                                       size_t workspace_bytes, int device, void *stream) {
+    return cbce_impl(logits, label, frame_numel, n_frames, size_average, grad_scale, nullptr, loss_out, grad, workspace,
+                     workspace_bytes, device, stream);
 }
 
 extern "C" int fosvos_cbce_loss_batch_counts(const float *logits, const float *label, int64_t numel, int size_average,
@@ -200,6 +220,6 @@ extern "C" int fosvos_cbce_loss_batch_counts(const float *logits, const float *l
                                              float *grad, void *workspace, size_t workspace_bytes, int device,
                                              void *stream) {
     FOSVOS_REQUIRE(batch_counts, FOSVOS_E_ARG, "cbce_loss_batch_counts: null batch_counts");
-    return cbce_impl(logits, label, numel, size_average, grad_scale, batch_counts, loss_out, grad, workspace,
+    return cbce_impl(logits, label, numel, 1, size_average, grad_scale, batch_counts, loss_out, grad, workspace,
                      workspace_bytes, device, stream);
 }

@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 CONV_RELU = 1
 CONV_OUT_F32 = 2
 
@@ -45,7 +45,7 @@ class VggGrads(ctypes.Structure):
     """fosvos_vgg_grads."""
     _fields_ = [("conv_w", _P13), ("conv_b", _P13), ("side_w", _P4), ("side_b", _P4),
                 ("dsn_w", c_void_p), ("dsn_b", c_void_p), ("fuse_w", c_void_p), ("fuse_b", c_void_p),
-                ("accumulate", c_int), ("defer_join", c_int), ("bucket_events", c_int)]
+                ("accumulate", c_int), ("defer_join", c_int), ("bucket_events", c_int), ("last_pass_of_cycle", c_int)]
 
 class ProfileRecord(ctypes.Structure):
     """fosvos_profile_record."""
@@ -122,6 +122,8 @@ SIGNATURES = {
     "fosvos_cbce_loss": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
                                  c_int, c_void_p]),
     "fosvos_cbce_workspace_bytes": (c_size_t, [c_int64]),
+    "fosvos_cbce_loss_frames": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                        c_size_t, c_int, c_void_p]),
     "fosvos_cbce_loss_batch_counts": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_size_t, c_int, c_void_p]),
     "fosvos_sgd_momentum_step": (c_int, [c_void_p, c_int, c_int64, c_float, c_int, c_int, c_void_p]),

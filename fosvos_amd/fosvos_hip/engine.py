@@ -433,6 +433,7 @@ def native_backward(P, packs, saved, d_outs, inplace: bool, defer_join: bool = F
     aux = packs.arenas.aux_stream(dev.index if dev.index is not None else torch.cuda.current_device())
     g.defer_join = 1 if (defer_join and inplace and aux) else 0
     g.bucket_events = 1 if getattr(packs, "publish_grad_buckets", False) else 0
+    g.last_pass_of_cycle = 1 if getattr(packs, "last_pass_of_cycle", False) else 0
     if d_fused is not None:
         d_fused = d_fused.contiguous().float()
         hold.append(d_fused)

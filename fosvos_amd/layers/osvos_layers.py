@@ -69,21 +69,15 @@ def class_balanced_cross_entropy_loss(output, label, size_average=True, batch_co
 
 
 class _CBCELossFrames(torch.autograd.Function):
-    """The loss of every frame of a batch on its own ([N,1,H,W] -> [N]): N launches of the fused loss kernel, gradients
-    in one buffer so that backward is a single scale."""
+    """The loss of every frame of a batch on its own ([N,1,H,W] -> [N]): one set of launches (fosvos_cbce_loss_frames),
+    gradients in one buffer so that backward is a single scale."""
 
     @staticmethod
     def forward(ctx, output, label, size_average):
-        output, label = output.contiguous().float(), label.contiguous().float()
-        n = output.shape[0]
-        losses, grads = [], []
-        for i in range(n):
-            loss, grad = ops.cbce_loss(output[i:i + 1], label[i:i + 1], size_average=bool(size_average),
-                                       want_grad=output.requires_grad)
-            losses.append(loss)
-            grads.append(grad)
-        ctx.grad = torch.cat(grads) if grads[0] is not None else None
-        return torch.stack(losses)
+        losses, grad = ops.cbce_loss_frames(output.contiguous().float(), label.contiguous().float(),
+                                            size_average=bool(size_average), want_grad=output.requires_grad)
+        ctx.grad = grad
+        return losses
 
     @staticmethod
     def backward(ctx, g):

@@ -97,6 +97,16 @@ class OSVOS_VGG(nn.Module):
         ``wait_grad_bucket`` - what the data-parallel loops overlap their bucketed all-reduce with."""
         self._packs.publish_grad_buckets = bool(value)
 
+    @property
+    def last_pass_of_cycle(self):
+        return getattr(self._packs, "last_pass_of_cycle", False)
+
+    @last_pass_of_cycle.setter
+    def last_pass_of_cycle(self, value):
+        """Hint for the next backward pass: no forward pass follows it before the optimizer step, so its trailing
+        weight-gradient kernels may take the whole chip (the training loops set it around a cycle's last pass)."""
+        self._packs.last_pass_of_cycle = bool(value)
+
     def wait_grad_bucket(self, bucket, stream=None):
         """Make `stream` (default: the current one) wait for gradient bucket `bucket` (``parallel.VGG_BUCKETS`` order) of
         the last backward pass run with ``publish_grad_buckets``; returns at once on the host."""

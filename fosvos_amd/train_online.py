@@ -199,7 +199,10 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         # reference: `loss /= nAveGrad; loss.backward()` (src/train_online.py:92-93).  Seeding the backward pass with
         # 1/nAveGrad is the same gradient (the division's own backward produces exactly this factor) without the
         # three tiny kernels of the division, the ones-fill and its backward on the critical path
-        last_of_cycle = world > 1 and (counter_gradient + k) % local_accum == 0
+        closes_cycle = (counter_gradient + k) % local_accum == 0
+        last_of_cycle = world > 1 and closes_cycle
+        if hasattr(net, 'last_pass_of_cycle'):
+            net.last_pass_of_cycle = closes_cycle
         if last_of_cycle:
             sync.arm()
         loss.backward(inv_avg)

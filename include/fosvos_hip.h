@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 9
+#define FOSVOS_ABI_VERSION 10
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -224,6 +224,14 @@ int fosvos_cbce_loss(const float *logits, const float *label, int64_t numel, int
                      float *loss_out, float *grad, void *workspace, size_t workspace_bytes, int device,
                      void *stream);
 size_t fosvos_cbce_workspace_bytes(int64_t numel);
+/* The loss of EVERY FRAME of a batch separately, in one set of launches: logits / label / grad are [n_frames][frame_numel],
+ * loss_out gets n_frames values, each what fosvos_cbce_loss returns for that frame alone (own class counts).  The online
+ * loop uses it when it runs several micro-batches of an accumulation cycle as one batched pass: the reference computes
+ * the loss per frame (src/train_online.py:80 on a [1,1,H,W] tensor).  frame_numel must be a multiple of 4 when
+ * n_frames > 1; workspace: n_frames x fosvos_cbce_workspace_bytes. */
+int fosvos_cbce_loss_frames(const float *logits, const float *label, int64_t frame_numel, int n_frames, int size_average,
+                            float grad_scale, float *loss_out, float *grad, void *workspace, size_t workspace_bytes,
+                            int device, void *stream);
 /* The same loss on ONE SHARD of a batch that is split over data-parallel ranks.  The reference counts positives /
  * negatives over the whole batch tensor (src/layers/osvos_layers.py:28-39), so the class weights of a shard must
  * come from the whole batch: batch_counts = DEVICE double[2] {positives, pixels} summed over all shards (the caller
@@ -392,6 +400,11 @@ typedef struct fosvos_vgg_grads {
     int bucket_events;            /* != 0: publish the gradients in three pieces as the pass finishes them (stage 5,
                                    * stage 4, the rest) so that a data-parallel caller can start each piece's
                                    * all-reduce early: see fosvos_vgg_grad_bucket_wait. */
+    int last_pass_of_cycle;       /* != 0: a hint - no forward pass follows this backward pass before the optimizer step
+                                   * (the last one of an accumulation cycle), so the weight-gradient kernels of the first
+                                   * two stages, which run after the data-gradient chain has ended, may take the whole
+                                   * chip (256 pixel splits instead of the shared-chip count).  Results differ only in
+                                   * the order of the fp32 sums over splits. */
 } fosvos_vgg_grads;
 
 size_t fosvos_vgg_arena_bytes(int N, int H, int W);

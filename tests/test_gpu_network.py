@@ -398,6 +398,29 @@ def test_loss_on_batch_shards_with_batch_counts():
     assert abs(cbce(x, gt, size_average=False).item() - ref.item()) <= 1e-5 * abs(ref.item())
 
 
+@pytest.mark.parametrize("h,w", [(40, 70), (33, 47)])
+def test_per_frame_loss_of_a_batch(h, w):
+    """class_balanced_cross_entropy_loss_frames == the loss called frame by frame, bit for bit (values and gradients);
+    33 x 47 frames (element count not a multiple of 4) take the one-call-per-frame route."""
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    from layers.osvos_layers import class_balanced_cross_entropy_loss_frames as cbce_frames
+    x = torch.randn(3, 1, h, w, generator=torch.Generator().manual_seed(5)).to(DEV).requires_grad_(True)
+    _, gt = O.synthetic_frame(3, h, w, seed=25)
+    gt = gt.to(DEV)
+    gt[2] = 0
+    for size_average in (False, True):
+        losses = cbce_frames(x, gt, size_average=size_average)
+        assert tuple(losses.shape) == (3,)
+        weights = torch.tensor([0.2, 1.0, 3.0], device=DEV)
+        g_batched, = torch.autograd.grad((losses * weights).sum(), x)
+        for i in range(3):
+            xi = x[i:i + 1].detach().clone().requires_grad_(True)
+            li = cbce(xi, gt[i:i + 1].clone(), size_average=size_average)
+            gi, = torch.autograd.grad(li * weights[i], xi)
+            assert torch.equal(li.detach(), losses[i].detach())
+            assert torch.equal(gi, g_batched[i:i + 1])
+
+
 def test_gradient_buckets_are_published_in_completion_order():
     """The hook the data-parallel loops overlap their all-reduce with: after a backward pass run with
     publish_grad_buckets, a side stream that waits for bucket b sees that bucket's final gradients (stage 5 first),
