@@ -17,6 +17,8 @@
 //   B  [9 taps][4 k-groups][BN channels]  slot = (tap*4 + kg) * BN + co
 // A ds_read_b128 fragment read (lane l: row l&15, k-group l>>4) then touches, per 16-lane service
 // group, 16 distinct slots of the 256-byte bank row for ANY base pixel: conflict-free for all taps.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 using namespace fosvos;
@@ -583,12 +585,13 @@ ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
         if (pixels >= 256 * 256) { p.tile = kSide; nb = blocks(8, 32, 16); }
         else { p.tile = kSideS; nb = blocks(4, 16, 16); }
     }
-#ifdef FOSVOS_STAMP
-    if (const char *e = getenv("FOSVOS_FORCE_TILE")) {  // lab only
-        p.tile = (TileId)atoi(e);
-        nb = p.tile == kBig ? blocks(8, 32, 64) : p.tile == kMid ? blocks(8, 16, 64) : blocks(4, 16, 64);
+    if (out_ch % 64 == 0) {
+        static const char *force = getenv("FOSVOS_FORCE_TILE");  // lab switch: 0 = 8x32, 1 = 8x16, 2 = 4x16 pixel tiles
+        if (force) {
+            p.tile = (TileId)atoi(force);
+            nb = p.tile == kBig ? blocks(8, 32, 64) : p.tile == kMid ? blocks(8, 16, 64) : blocks(4, 16, 64);
+        }
     }
-#endif
     int ks = 1;
     if (nb < kMinBlocks * 3 / 4) {
         ks = (int)cdiv(kMinBlocks / 2, nb);  // one workgroup per CU is enough (measured at 30x54x512: 2 splits beat 4)

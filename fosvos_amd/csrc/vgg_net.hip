@@ -5,6 +5,8 @@
 //
 // Why native: driven from Python, each of the ~100 ops of a training step costs ~19 us of interpreter, ctypes
 // marshalling and allocator time (1.8 ms/step - as much as the GPU needs); from C++ a launch costs ~3 us.
+#include <stdlib.h>
+
 #include <mutex>
 
 #include "common.hpp"
@@ -193,6 +195,7 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
     const bool buckets = g->bucket_events != 0;
     // the weight gradients of stages 1-2 come last; after the cycle's LAST backward pass nothing runs beside them
     const bool tail = g->last_pass_of_cycle != 0;
+    static const int tail_stages = getenv("FOSVOS_TAIL_STAGES") ? atoi(getenv("FOSVOS_TAIL_STAGES")) : 1;  // lab switch
     if (par || buckets) {
         FOSVOS_ENTER(device);
         FOSVOS_TRY(get_events(device, &ev, &pool));
@@ -245,7 +248,7 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
             // side_prep[s-1]: wgrad from (stage output, d_side) on the wgrad stream; its dgrad into the stage-output
             // gradient: ReLU-masked and added to what came back through the next stage's pool (already in gact[last])
             FOSVOS_TRY(wgrad_impl(act(last), dside[s - 1], g->side_w[s - 1], g->side_b[s - 1], N, hh, ww, kStageCh[s], 16,
-                                  acc, base + a.wsa_side[s - 1], a.wsa_side_bytes[s - 1], device, sa, &reduce, tail && s <= 1));
+                                  acc, base + a.wsa_side[s - 1], a.wsa_side_bytes[s - 1], device, sa, &reduce, tail && s <= tail_stages));
             const uint16_t *addend = (s < 4) ? gact(last) : nullptr;
             if (par && s < 4) FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[16 + s - 1], 0));  // d_side[s-1] from the wgrad stream
             FOSVOS_TRY(fosvos_conv3x3_dgrad(dside[s - 1], w->side_wd[s - 1], act(last), addend, gact(last), N, hh, ww,
@@ -269,14 +272,14 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
             const bool middle = (last - first == 2) && c == last - 1;
             if (!middle)
                 FOSVOS_TRY(wgrad_impl(xin, gact(c), g->conv_w[c], g->conv_b[c], N, hh, ww, kCin[c], kCout[c], acc,
-                                      base + a.wsa_conv[c], a.wsa_conv_bytes[c], device, sa, &reduce, tail && s <= 1));
+                                      base + a.wsa_conv[c], a.wsa_conv_bytes[c], device, sa, &reduce, tail && s <= tail_stages));
             FOSVOS_TRY(fosvos_conv3x3_dgrad(gact(c), w->conv_wd[c], mask, nullptr, dx, N, hh, ww, kCin[c], kCout[c], ws,
                                             a.ws_bytes, device, sm));
             const bool skip_event = (last - first == 2) && c == last;  // gact(last-1): covered by the middle conv's event
             if (!from_pool && !skip_event) FOSVOS_TRY(publish(c - 1));
             if (middle)
                 FOSVOS_TRY(wgrad_impl(xin, gact(c), g->conv_w[c], g->conv_b[c], N, hh, ww, kCin[c], kCout[c], acc,
-                                      base + a.wsa_conv[c], a.wsa_conv_bytes[c], device, sa, &reduce, tail && s <= 1));
+                                      base + a.wsa_conv[c], a.wsa_conv_bytes[c], device, sa, &reduce, tail && s <= tail_stages));
         }
         if (s > 0)  // pool backward into the previous stage's output gradient, its ReLU mask fused
             FOSVOS_TRY(fosvos_maxpool2x2_ceil_bwd(act(kLastOfStage[s - 1]), reinterpret_cast<const uint16_t *>(base + a.gpooled[s - 1]),

@@ -37,21 +37,22 @@ def main():
     filt = sys.argv[2] if len(sys.argv) > 2 else ""
     which = (sys.argv[3] if len(sys.argv) > 3 else "fwd,dgrad,wgrad").split(",")
     dev = "cuda:0"
+    nb = int(os.environ.get("BENCH_CONV_N", "1"))  # frames per launch
     g = torch.Generator(device=dev).manual_seed(0)
     print(f"{'layer':9s} {'op':6s} {'us':>9s} {'TFLOP/s':>9s}")
     tot = {}
     for name, H, W, ci, co in LAYERS:
         if filt and filt not in name:
             continue
-        x = torch.randn(1, H, W, ci, device=dev, generator=g).to(torch.bfloat16)
+        x = torch.randn(nb, H, W, ci, device=dev, generator=g).to(torch.bfloat16)
         w = torch.randn(co, ci, 3, 3, device=dev, generator=g) * (2.0 / (9 * ci)) ** 0.5
         b = torch.randn(co, device=dev, generator=g) * 0.1
         wf, wd = ops.pack_conv3x3_weights(w)
         cy = (co + 31) // 32 * 32
-        dy = torch.randn(1, H, W, cy, device=dev, generator=g).to(torch.bfloat16)
+        dy = torch.randn(nb, H, W, cy, device=dev, generator=g).to(torch.bfloat16)
         if cy != co:
             dy[..., co:] = 0
-        flop = 2.0 * H * W * 9 * ci * co
+        flop = 2.0 * nb * H * W * 9 * ci * co
         side = co == 16
         res = {}
         if "fwd" in which:
