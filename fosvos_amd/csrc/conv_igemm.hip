@@ -80,8 +80,9 @@ struct Tile {
     static constexpr int MF = WAVE_M / 16, NF = WAVE_N / 16;
     static constexpr int A_SLOTS = 4 * NPIX_PAD;
     static constexpr int B_SLOTS = 36 * BN;
-    static constexpr int A_IT = (NPIX8 * 4 + 255) / 256;
-    static constexpr int B_IT = (B_SLOTS + 255) / 256;
+    static constexpr int NT = 64 * WM * WN;  // threads per workgroup
+    static constexpr int A_IT = (NPIX8 * 4 + NT - 1) / NT;
+    static constexpr int B_IT = (B_SLOTS + NT - 1) / NT;
     static constexpr int OUT_LD = BN + 8;  // bf16 elements per staged output row (16-B aligned rows)
     static constexpr int LDS_MAIN = (A_SLOTS + B_SLOTS) * 16;
     static constexpr int LDS_OUT = BM * OUT_LD * 2;
@@ -90,8 +91,8 @@ struct Tile {
 #define FOSVOS_MID_WPE 3
 #endif
     // resident workgroups per CU (= waves per SIMD): what 160 KB of LDS allows, at most 2 for the 256-px tiles
-    static constexpr int WPE = (BM >= 256 || BN < 64) ? 2 : FOSVOS_MID_WPE;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static constexpr int WPE = (BM >= 256 || BN < 64) ? 2 : FOSVOS_MID_WPE;  // (an 8-wave workgroup fills two by itself)
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
     static_assert(TW % 16 == 0 && WAVE_M % 16 == 0 && WAVE_N % 16 == 0, "fragment alignment");
     static_assert(BM % WM == 0 && BN % WN == 0, "wave split");
 };
@@ -131,7 +132,7 @@ __device__ __forceinline__ void sched_tap() {
 // waves_per_eu(2,2): two workgroups per CU, up to 256 registers each - without the cap hipcc spills the
 // prefetched chunk to scratch to reach an occupancy the LDS image would not allow anyway
 template <class T, bool OUT_F32>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))) void k_conv3x3_igemm(const ConvArgs a) {
+__global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE))) void k_conv3x3_igemm(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     uint4 *sA = smem;
     uint4 *sB = smem + T::A_SLOTS;
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))
     unsigned a_ok = 0;  // bit it: the element is a real image pixel (otherwise zero padding)
 #pragma unroll
     for (int it = 0; it < T::A_IT; ++it) {
-        const int idx = it * 256 + tid;
+        const int idx = it * T::NT + tid;
         const int oct = idx >> 5, within = idx & 31;
         const int kg = within >> 3;
         const int P = oct * 8 + (within & 7);
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))
     auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(xn), 0, x_bytes, 0x00020000);
     auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.w) + (int64_t)n0 * 8, 0, w_bytes,
                                                     0x00020000);
-    static_assert(256 % T::BN == 0, "weight staging assumes BN divides the workgroup size");
+    static_assert(T::NT % T::BN == 0, "weight staging assumes BN divides the workgroup size");
     const int b_voff = ((tid / T::BN) * a.Co_pad + tid % T::BN) * 16;
     const int b_row_bytes = a.Co_pad * 16;
 #define FOSVOS_LD_A(i)                                                                                  \
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))
 #define FOSVOS_LD_B(i)                                                                                  \
     if constexpr (i < T::B_IT)                                                                          \
         pb##i = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(                        \
-            w_rsrc, b_voff, (cc_ * 36 + i * (256 / T::BN)) * b_row_bytes, 0));
+            w_rsrc, b_voff, (cc_ * 36 + i * (T::NT / T::BN)) * b_row_bytes, 0));
 #define FOSVOS_LOAD_CHUNK(cc_expr)                                                                      \
     {                                                                                                   \
         const int cc_ = (cc_expr);                                                                      \
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))
     }
 #define FOSVOS_ST_B(i)                                                                                  \
     if constexpr (i < T::B_IT) {                                                                        \
-        if (i * 256 + tid < T::B_SLOTS) sB[i * 256 + tid] = pb##i;                                      \
+        if (i * T::NT + tid < T::B_SLOTS) sB[i * T::NT + tid] = pb##i;                                  \
     }
 #define FOSVOS_STORE_CHUNK()                                                                            \
     {                                                                                                   \
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))
     FOSVOS_STAMP_AT(9)
     constexpr int VEC_PER_PIX = T::BN / 8;
     constexpr int OUT_N = T::BM * VEC_PER_PIX;      // 16-byte output vectors of the tile
-    constexpr int OUT_IT = (OUT_N + 255) / 256;     // ... per thread
+    constexpr int OUT_IT = (OUT_N + T::NT - 1) / T::NT;  // ... per thread
     uint16_t *yo = reinterpret_cast<uint16_t *>(a.y);
     if (a.relu_src || a.addend) {
         // dgrad: ReLU mask of the producing layer and the other consumer's gradient.  ALL of a thread's mask / addend
@@ -383,10 +384,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))
         uint4 mk[OUT_IT], ad[OUT_IT];
 #pragma unroll
         for (int it = 0; it < OUT_IT; ++it) {
-            const int idx = min(it * 256 + tid, OUT_N - 1);
+            const int idx = min(it * T::NT + tid, OUT_N - 1);
             const int pix = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
             const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
-            ok[it] = it * 256 + tid < OUT_N && gy < H && gx < W;
+            ok[it] = it * T::NT + tid < OUT_N && gy < H && gx < W;
             off[it] = (((int64_t)n * H + min(gy, H - 1)) * W + min(gx, W - 1)) * a.Cout + n0 + cg * 8;
             mk[it] = ad[it] = make_uint4(0, 0, 0, 0);
         }
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))
         }
 #pragma unroll
         for (int it = 0; it < OUT_IT; ++it) {
-            const int idx = min(it * 256 + tid, OUT_N - 1);
+            const int idx = min(it * T::NT + tid, OUT_N - 1);
             const int pix = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
             float f[8];
             unpack8(*reinterpret_cast<const uint4 *>(sO + pix * T::OUT_LD + cg * 8), f);
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))
     } else {
 #pragma unroll
         for (int it = 0; it < OUT_IT; ++it) {
-            const int idx = it * 256 + tid;
+            const int idx = it * T::NT + tid;
             if (idx >= OUT_N) continue;
             const int pix = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
             const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, T::WPE))
         static_assert(T::TH % 2 == 0 && T::TW % 2 == 0, "pooling windows must not straddle tiles");
         constexpr int PW = T::TW / 2, PN = (T::TH / 2) * PW;
         const int OH = (H + 1) >> 1, OW = (W + 1) >> 1;
-        for (int idx = tid; idx < PN * VEC_PER_PIX; idx += 256) {
+        for (int idx = tid; idx < PN * VEC_PER_PIX; idx += T::NT) {
             const int pp = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
             const int py = pp / PW, px = pp % PW;
             const int oy = (y0 >> 1) + py, ox = (x0 >> 1) + px;
@@ -545,6 +546,8 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int64
 }
 
 // tile configurations
+// (Tile<16, 32, 64, 8, 1>, 512 px x 64 ch on eight waves, loads a chunk's weight tile once per 512 pixels: -35 % staging bytes,
+// and 5-15 % SLOWER on every layer at three frames per launch (895 vs 966 frames/s on the step): the template takes it as is)
 using TileBig = Tile<8, 32, 64, 4, 1>;    // 256 px x 64 ch
 using TileMid = Tile<8, 16, 64, 2, 2>;    // 128 px x 64 ch
 using TileSmall = Tile<4, 16, 64, 2, 2>;  //  64 px x 64 ch
@@ -587,7 +590,7 @@ ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
     }
     if (out_ch % 64 == 0) {
         static const char *force = getenv("FOSVOS_FORCE_TILE");  // lab switch: 0 = 8x32, 1 = 8x16, 2 = 4x16 pixel tiles
-        if (force) {
+        if (force && atoi(force) >= 0 && atoi(force) <= 2) {
             p.tile = (TileId)atoi(force);
             nb = p.tile == kBig ? blocks(8, 32, 64) : p.tile == kMid ? blocks(8, 16, 64) : blocks(4, 16, 64);
         }
@@ -620,6 +623,16 @@ int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st, int in_ch) 
 #endif
     const int64_t tiles = (int64_t)a.tiles_x * a.tiles_y * a.N;
     FOSVOS_REQUIRE(tiles <= 0x7fffffff && a.Cout % T::BN == 0, FOSVOS_E_SHAPE, "conv3x3: tile grid");
+    if constexpr (T::LDS_BYTES > 64 * 1024) {  // opt in to more than 64 KB of dynamic LDS, once per device
+        static bool once[64];
+        int dev = 0;
+        FOSVOS_HIP_CHECK(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !once[dev]) {
+            FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_igemm<T, OUT_F32>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+            once[dev] = true;
+        }
+    }
     if (g_prof_on) {  // the name rocprofv3 prints for this instantiation
         static char name[80];
         snprintf(name, sizeof(name), "k_conv3x3_igemm<Tile<%d, %d, %d, %d, %d>, %s>", T::TH, T::TW, T::BN, T::WM, T::WN,
@@ -627,7 +640,7 @@ int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st, int in_ch) 
         prof_begin(name, st, 2.0 * a.N * a.H * a.W * 9.0 * in_ch * a.Cout);
     }
     hipLaunchKernelGGL((k_conv3x3_igemm<T, OUT_F32>),
-                       dim3((unsigned)tiles, (unsigned)(a.Cout / T::BN), (unsigned)plan.k_splits), dim3(256),
+                       dim3((unsigned)tiles, (unsigned)(a.Cout / T::BN), (unsigned)plan.k_splits), dim3(T::NT),
                        T::LDS_BYTES, st, a);
     FOSVOS_LAUNCH_CHECK();
     if (plan.k_splits > 1) {
