@@ -201,9 +201,10 @@ def main():
         run(args.warmup)
         barrier()
         t0 = time.perf_counter()
-        run(args.steps)
+        ret = run(args.steps)
         barrier()
         elapsed = time.perf_counter() - t0
+        host_lead[mode] = ret.get("seconds_host_enqueue")
         if world > 1:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -211,6 +212,7 @@ def main():
         train_online.data_parallel = False
         return elapsed, prov, opt, run
 
+    host_lead = {}  # per mode: seconds the host loop needed to ENQUEUE the timed steps (the device finishes later)
     modes = ["single"] if world == 1 else (["dp", "replicas"] if args.mode == "both" else [args.mode])
     results = {}
     for m in modes:
@@ -234,6 +236,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1000.0,
+        "host_enqueue_ms_per_step": (host_lead.get(head) or 0.0) / args.steps * 1000.0,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -73,20 +73,22 @@ class FusedSGD(optim.SGD):
             return loss
         n = len(entries)
         nbytes = n * ctypes.sizeof(SgdEntry)
-        if self._host_table is None or self._host_table.numel() < nbytes:
-            self._host_table = torch.empty(max(nbytes, 4096), dtype=torch.uint8).pin_memory()
-            self._dev_table = torch.empty(max(nbytes, 4096), dtype=torch.uint8, device=device)
-        arr = (SgdEntry * n).from_address(self._host_table.data_ptr())
-        for i, e in enumerate(entries):
-            arr[i].param, arr[i].grad, arr[i].momentum_buf, arr[i].numel, arr[i].lr, arr[i].weight_decay = e
-        # NB: the pinned staging buffer is rewritten on the next step(); the copy below is stream-ordered before
-        # the kernel, and the next step's host write happens after this step's copy was issued - to be safe against
-        # an in-flight copy we synchronise on the copy event only when a previous one is still pending.
-        if getattr(self, "_copy_event", None) is not None:
-            self._copy_event.synchronize()
-        self._dev_table[:nbytes].copy_(self._host_table[:nbytes], non_blocking=True)
-        self._copy_event = torch.cuda.Event()
-        self._copy_event.record()
+        # The device-side table only changes when a pointer, a size or a group's lr / weight decay does (the online loop:
+        # never after its first step) - it is rebuilt and re-sent only then.  A rebuild rewrites the pinned staging
+        # buffer, so it first waits for the previous upload to have been consumed.
+        if entries != getattr(self, "_sent_entries", None):
+            if self._host_table is None or self._host_table.numel() < nbytes:
+                self._host_table = torch.empty(max(nbytes, 4096), dtype=torch.uint8).pin_memory()
+                self._dev_table = torch.empty(max(nbytes, 4096), dtype=torch.uint8, device=device)
+            if getattr(self, "_copy_event", None) is not None:
+                self._copy_event.synchronize()
+            arr = (SgdEntry * n).from_address(self._host_table.data_ptr())
+            for i, e in enumerate(entries):
+                arr[i].param, arr[i].grad, arr[i].momentum_buf, arr[i].numel, arr[i].lr, arr[i].weight_decay = e
+            self._dev_table[:nbytes].copy_(self._host_table[:nbytes], non_blocking=True)
+            self._copy_event = torch.cuda.Event()
+            self._copy_event.record()
+            self._sent_entries = entries
         idx = device.index if device.index is not None else torch.cuda.current_device()
         check(lib().fosvos_sgd_momentum_step(self._dev_table.data_ptr(), n, max_numel, momentum, 0, idx,
                                              torch.cuda.current_stream(idx).cuda_stream), "sgd_momentum_step")

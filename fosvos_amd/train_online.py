@@ -248,6 +248,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
 
     net.defer_wgrad_join = False  # joins
     net.compute_side_outputs = True
+    time_enqueued = timeit.default_timer() - time_all_start  # how far ahead of the device the host loop ran
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     flush_logs(True)
@@ -256,7 +257,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     log.info('Train {0}: total time {1} sec'.format(seq_name, str(time_for_all)))
     log.info('Train {0}: {1} images'.format(seq_name, str(n_images)))
     log.info('Train {0}: time per sample {1} sec'.format(seq_name, str(time_for_all / max(n_images, 1))))
-    return {'loss': loss_tr, 'seconds': time_for_all, 'iterations': n_iters}
+    return {'loss': loss_tr, 'seconds': time_for_all, 'iterations': n_iters, 'seconds_host_enqueue': time_enqueued}
 
 
 def main(argv=None):
