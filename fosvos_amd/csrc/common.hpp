@@ -114,9 +114,17 @@ __device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even, N
     return __builtin_bit_cast(uint16_t, b);
 }
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// two floats -> two bf16 in one register: ONE v_cvt_pk_bf16_f32 (the scalar form costs two converts + shift + or)
+typedef float fosvos_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 fosvos_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const fosvos_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, fosvos_bf16x2));
 }
+// max(v, 0) as ONE instruction: a signed-integer max on the float's bits (negative floats are negative integers; -0 -> +0).
+// fmaxf costs a canonicalising v_max per operand in front of the max itself.  A NaN with the sign bit clear passes through
+// (as torch.relu would have it), one with the sign bit set becomes 0.
+__device__ __forceinline__ float relu_f(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
 __device__ __forceinline__ void unpack8(const uint4 &v, float (&f)[8]) {
     f[0] = __uint_as_float(v.x << 16);
     f[1] = __uint_as_float(v.x & 0xffff0000u);
@@ -134,6 +142,31 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     v.z = pack2bf(f[4], f[5]);
     v.w = pack2bf(f[6], f[7]);
     return v;
+}
+
+// ---- packed bf16 pairs handled as 16-bit integers (v_pk_*_i16/u16: one instruction per two elements, no unpack / repack)
+typedef short fosvos_i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short fosvos_u16x2 __attribute__((ext_vector_type(2)));
+// per element: f where m > 0, else +0.  A bf16 is > 0 exactly when its bits, read as int16, are > 0 (NaNs aside).
+__device__ __forceinline__ uint32_t keep_where_pos_bf16x2(uint32_t f, uint32_t m) {
+    const fosvos_i16x2 zero = {0, 0}, one = {1, 1};
+    const fosvos_i16x2 t = __builtin_elementwise_min(
+        __builtin_elementwise_max(__builtin_bit_cast(fosvos_i16x2, m), zero), one);  // 1 where m > 0
+    const fosvos_u16x2 all = {0xffff, 0xffff};
+    return f & __builtin_bit_cast(uint32_t, __builtin_bit_cast(fosvos_u16x2, t) * all);
+}
+__device__ __forceinline__ uint4 keep_where_pos_bf16x8(const uint4 &f, const uint4 &m) {
+    return make_uint4(keep_where_pos_bf16x2(f.x, m.x), keep_where_pos_bf16x2(f.y, m.y),
+                      keep_where_pos_bf16x2(f.z, m.z), keep_where_pos_bf16x2(f.w, m.w));
+}
+// per element max of NON-NEGATIVE bf16 values (post-ReLU maps): their bit patterns order like unsigned integers
+__device__ __forceinline__ uint32_t max_nonneg_bf16x2(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(fosvos_u16x2, a),
+                                                                 __builtin_bit_cast(fosvos_u16x2, b)));
+}
+__device__ __forceinline__ uint4 max_nonneg_bf16x8(const uint4 &a, const uint4 &b) {
+    return make_uint4(max_nonneg_bf16x2(a.x, b.x), max_nonneg_bf16x2(a.y, b.y), max_nonneg_bf16x2(a.z, b.z),
+                      max_nonneg_bf16x2(a.w, b.w));
 }
 
 // wave64 all-lanes sum

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_first_fwd(const float *__restrict__ fra
         if (gx < W) {
             float o[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = fmaxf(acc[p][j], 0.f);
+            for (int j = 0; j < 8; ++j) o[j] = relu_f(acc[p][j]);
             *reinterpret_cast<uint4 *>(y + (((int64_t)n * H + gy) * W + gx) * CO + cg * 8) = pack8(o);
         }
     }

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
                     float4 v = make_float4(acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z,
                                            acc[i][j][3] + b.w);
                     if (a.flags & FOSVOS_CONV_RELU)
-                        v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                        v = make_float4(relu_f(v.x), relu_f(v.y), relu_f(v.z), relu_f(v.w));
                     *reinterpret_cast<float4 *>(yo + (((int64_t)n * H + gy) * W + gx) * a.Cout + co) = v;
                 }
             }
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
             const int pix = wm * T::WAVE_M + i * 16 + cl;
             float v0 = acc[i][j][0] + b.x, v1 = acc[i][j][1] + b.y, v2 = acc[i][j][2] + b.z, v3 = acc[i][j][3] + b.w;
             if (a.flags & FOSVOS_CONV_RELU) {
-                v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+                v0 = relu_f(v0); v1 = relu_f(v1); v2 = relu_f(v2); v3 = relu_f(v3);
             }
             *reinterpret_cast<uint2 *>(sO + pix * T::OUT_LD + col) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
         }
@@ -403,25 +403,24 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
         for (int it = 0; it < OUT_IT; ++it) {
             const int idx = min(it * T::NT + tid, OUT_N - 1);
             const int pix = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
-            float f[8];
-            unpack8(*reinterpret_cast<const uint4 *>(sO + pix * T::OUT_LD + cg * 8), f);
-            if (a.relu_src) {
-                float m[8];
-                unpack8(mk[it], m);
+            uint4 v = *reinterpret_cast<const uint4 *>(sO + pix * T::OUT_LD + cg * 8);
+            if (a.relu_src) v = keep_where_pos_bf16x8(v, mk[it]);  // the ReLU mask, on the packed pairs
+            if (a.addend || (a.flags & kReluAfterAdd)) {
+                float f[8];
+                unpack8(v, f);
+                if (a.addend) {
+                    float av[8];
+                    unpack8(ad[it], av);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = m[e] > 0.f ? f[e] : 0.f;
-            }
-            if (a.addend) {
-                float av[8];
-                unpack8(ad[it], av);
+                    for (int e = 0; e < 8; ++e) f[e] += av[e];
+                }
+                if (a.flags & kReluAfterAdd) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] += av[e];
+                    for (int e = 0; e < 8; ++e) f[e] = relu_f(f[e]);
+                }
+                v = pack8(f);
             }
-            if (a.flags & kReluAfterAdd) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
-            }
-            if (ok[it]) *reinterpret_cast<uint4 *>(yo + off[it]) = pack8(f);
+            if (ok[it]) *reinterpret_cast<uint4 *>(yo + off[it]) = v;
         }
     } else {
 #pragma unroll
@@ -450,6 +449,18 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
             const int py = pp / PW, px = pp % PW;
             const int oy = (y0 >> 1) + py, ox = (x0 >> 1) + px;
             if (oy >= OH || ox >= OW) continue;
+            uint16_t *dst = a.y_pool + (((int64_t)n * OH + oy) * OW + ox) * a.Cout + n0 + cg * 8;
+            if (a.flags & FOSVOS_CONV_RELU) {  // the staged values are >= 0: the maximum is an integer max on the packed pairs
+                uint4 mx = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int ly = 2 * py + (t >> 1), lx = 2 * px + (t & 1);
+                    if (y0 + ly < H && x0 + lx < W)
+                        mx = max_nonneg_bf16x8(mx, *reinterpret_cast<const uint4 *>(sO + (ly * T::TW + lx) * T::OUT_LD + cg * 8));
+                }
+                *reinterpret_cast<uint4 *>(dst) = mx;
+                continue;
+            }
             float m[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
@@ -463,7 +474,7 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
                     for (int j = 0; j < 8; ++j) m[j] = f[j] > m[j] ? f[j] : m[j];
                 }
             }
-            *reinterpret_cast<uint4 *>(a.y_pool + (((int64_t)n * OH + oy) * OW + ox) * a.Cout + n0 + cg * 8) = pack8(m);
+            *reinterpret_cast<uint4 *>(dst) = pack8(m);
         }
     }
     FOSVOS_STAMP_AT(10)
@@ -512,7 +523,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int64
         }
         if (a.flags & FOSVOS_CONV_RELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+            for (int e = 0; e < 8; ++e) f[e] = relu_f(f[e]);
         }
         if (a.flags & FOSVOS_CONV_OUT_F32) {
             float *yo = reinterpret_cast<float *>(a.y) + off;
@@ -538,7 +549,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int64
             }
             if (a.flags & kReluAfterAdd) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+                for (int e = 0; e < 8; ++e) f[e] = relu_f(f[e]);
             }
         }
         *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(a.y) + i * 8) = pack8(f);
