@@ -108,6 +108,7 @@ typedef uint16_t bf16_t;  // storage type
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef unsigned int u32x4 __attribute__((__vector_size__(16)));  // data operand of the buffer store builtins
 
 __device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even, NaN stays NaN
     __bf16 b = (__bf16)f;

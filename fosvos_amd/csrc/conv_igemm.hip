@@ -153,11 +153,11 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
 
     // ---- A staging plan: 8 consecutive lanes = 8 consecutive pixels of one k-group (conflict-free
     // ds_write_b128), the 4 k-groups of those pixels in the next 3 octets (same 64-byte global runs)
-    // Loads are UNCONDITIONAL (addresses clamped into the image) and padding is applied as a select when the
-    // registers are written to LDS: a load under a branch makes hipcc drain vmcnt(0) inside the prefetch block.
+    // Loads are UNCONDITIONAL (a load under a branch makes hipcc drain vmcnt(0) inside the prefetch block); an element of the
+    // zero padding (or beyond the halo) gets the byte offset ~0, which the descriptor's range check turns into zeros - no
+    // select when the registers go to LDS (that was 24 of the ~40 vector-ALU instructions of a chunk).
     int a_goff[T::A_IT];
     int a_slot[T::A_IT];
-    unsigned a_ok = 0;  // bit it: the element is a real image pixel (otherwise zero padding)
 #pragma unroll
     for (int it = 0; it < T::A_IT; ++it) {
         const int idx = it * T::NT + tid;
@@ -165,17 +165,13 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
         const int kg = within >> 3;
         const int P = oct * 8 + (within & 7);
         a_slot[it] = -1;
-        int gy = y0, gx = x0;
+        a_goff[it] = -1;
         if (P < T::NPIX) {
             const int hy = P / T::HALO_W, hx = P - hy * T::HALO_W;
-            gy = y0 + hy - 1;
-            gx = x0 + hx - 1;
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
             a_slot[it] = kg * T::NPIX_PAD + P;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) a_ok |= 1u << it;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) a_goff[it] = ((gy * W + gx) * Cin + kg * 8) * 2;  // inside image n
         }
-        gy = min(max(gy, 0), H - 1);
-        gx = min(max(gx, 0), W - 1);
-        a_goff[it] = ((gy * W + gx) * Cin + kg * 8) * 2;  // byte offset inside image n
     }
 
     f32x4 acc[T::MF][T::NF];
@@ -234,12 +230,7 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
     }
 #define FOSVOS_ST_A(i)                                                                                  \
     if constexpr (i < T::A_IT) {                                                                        \
-        if (a_slot[i] >= 0) {                                                                           \
-            const bool ok_ = (a_ok >> i) & 1u;                                                          \
-            uint4 v_ = pa##i;                                                                           \
-            v_.x = ok_ ? v_.x : 0u; v_.y = ok_ ? v_.y : 0u; v_.z = ok_ ? v_.z : 0u; v_.w = ok_ ? v_.w : 0u; \
-            sA[a_slot[i]] = v_;                                                                         \
-        }                                                                                               \
+        if (a_slot[i] >= 0) sA[a_slot[i]] = pa##i;                                                      \
     }
 #define FOSVOS_ST_B(i)                                                                                  \
     if constexpr (i < T::B_IT) {                                                                        \
@@ -374,68 +365,81 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
     constexpr int VEC_PER_PIX = T::BN / 8;
     constexpr int OUT_N = T::BM * VEC_PER_PIX;      // 16-byte output vectors of the tile
     constexpr int OUT_IT = (OUT_N + T::NT - 1) / T::NT;  // ... per thread
+    // A thread's vectors are PIX_STEP pixels = ROW_STEP whole tile rows apart: same column and channel group, so every byte
+    // offset is the first one plus a wave-uniform row stride (one add per vector instead of a 64-bit multiply chain), and all
+    // global accesses of the epilogue are buffer operations on the image's own descriptor: 32-bit offsets, out-of-image
+    // vectors get the offset ~0 and are dropped (stores) or come back as zeros (loads) by the range check.
+    constexpr int PIX_STEP = T::NT / VEC_PER_PIX;
+    static_assert(T::NT % VEC_PER_PIX == 0 && PIX_STEP % T::TW == 0, "a thread's output vectors must share a column");
+    constexpr int ROW_STEP = PIX_STEP / T::TW;
+    const int o_cg = tid % VEC_PER_PIX, o_pix = tid / VEC_PER_PIX;
+    const int o_ly = o_pix / T::TW, o_gx = x0 + o_pix % T::TW;
+    const int img_bytes = H * W * a.Cout * 2;
     uint16_t *yo = reinterpret_cast<uint16_t *>(a.y);
-    if (a.relu_src || a.addend) {
-        // dgrad: ReLU mask of the producing layer and the other consumer's gradient.  ALL of a thread's mask / addend
-        // vectors are requested before the first one is used (unconditional loads from clamped addresses): rolled,
-        // this loop waited out one full memory latency per vector and operand (8 x 2 round trips per workgroup).
-        int64_t off[OUT_IT];
-        bool ok[OUT_IT];
-        uint4 mk[OUT_IT], ad[OUT_IT];
+    const uint16_t *s_vec = sO + o_pix * T::OUT_LD + o_cg * 8;  // this thread's first staged vector; the next is PIX_STEP rows of sO on
+    if (!(a.flags & kSubsample2)) {
+        int voff[OUT_IT];
 #pragma unroll
         for (int it = 0; it < OUT_IT; ++it) {
-            const int idx = min(it * T::NT + tid, OUT_N - 1);
-            const int pix = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
-            const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
-            ok[it] = it * T::NT + tid < OUT_N && gy < H && gx < W;
-            off[it] = (((int64_t)n * H + min(gy, H - 1)) * W + min(gx, W - 1)) * a.Cout + n0 + cg * 8;
-            mk[it] = ad[it] = make_uint4(0, 0, 0, 0);
+            const int gy = y0 + o_ly + it * ROW_STEP;
+            const bool ok = it * T::NT + tid < OUT_N && gy < H && o_gx < W;
+            voff[it] = ok ? ((gy * W + o_gx) * a.Cout + n0 + o_cg * 8) * 2 : -1;
         }
-        if (a.relu_src) {
+        auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(yo + (int64_t)n * H * W * a.Cout, 0, img_bytes, 0x00020000);
+        if (a.relu_src || a.addend) {
+            // dgrad: ReLU mask of the producing layer and the other consumer's gradient.  ALL of a thread's mask / addend
+            // vectors are requested before the first one is used: rolled, this loop waited out one full memory latency per
+            // vector and operand (8 x 2 round trips per workgroup).
+            uint4 mk[OUT_IT], ad[OUT_IT];
+            auto m_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint16_t *>(a.relu_src ? a.relu_src + (int64_t)n * H * W * a.Cout : yo), 0,
+                a.relu_src ? img_bytes : 0, 0x00020000);
+            auto ad_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint16_t *>(a.addend ? a.addend + (int64_t)n * H * W * a.Cout : yo), 0,
+                a.addend ? img_bytes : 0, 0x00020000);
 #pragma unroll
-            for (int it = 0; it < OUT_IT; ++it) mk[it] = *reinterpret_cast<const uint4 *>(a.relu_src + off[it]);
-        }
-        if (a.addend) {
+            for (int it = 0; it < OUT_IT; ++it)
+                mk[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(m_rsrc, voff[it], 0, 0));
 #pragma unroll
-            for (int it = 0; it < OUT_IT; ++it) ad[it] = *reinterpret_cast<const uint4 *>(a.addend + off[it]);
-        }
+            for (int it = 0; it < OUT_IT; ++it)
+                ad[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ad_rsrc, voff[it], 0, 0));
 #pragma unroll
-        for (int it = 0; it < OUT_IT; ++it) {
-            const int idx = min(it * T::NT + tid, OUT_N - 1);
-            const int pix = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
-            uint4 v = *reinterpret_cast<const uint4 *>(sO + pix * T::OUT_LD + cg * 8);
-            if (a.relu_src) v = keep_where_pos_bf16x8(v, mk[it]);  // the ReLU mask, on the packed pairs
-            if (a.addend || (a.flags & kReluAfterAdd)) {
-                float f[8];
-                unpack8(v, f);
-                if (a.addend) {
-                    float av[8];
-                    unpack8(ad[it], av);
+            for (int it = 0; it < OUT_IT; ++it) {
+                uint4 v = *reinterpret_cast<const uint4 *>(s_vec + it * PIX_STEP * T::OUT_LD);
+                if (a.relu_src) v = keep_where_pos_bf16x8(v, mk[it]);  // the ReLU mask, on the packed pairs
+                if (a.addend || (a.flags & kReluAfterAdd)) {
+                    float f[8];
+                    unpack8(v, f);
+                    if (a.addend) {
+                        float av[8];
+                        unpack8(ad[it], av);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] += av[e];
+                        for (int e = 0; e < 8; ++e) f[e] += av[e];
+                    }
+                    if (a.flags & kReluAfterAdd) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = relu_f(f[e]);
+                    }
+                    v = pack8(f);
                 }
-                if (a.flags & kReluAfterAdd) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = relu_f(f[e]);
-                }
-                v = pack8(f);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y_rsrc, voff[it], 0, 0);
             }
-            if (ok[it]) *reinterpret_cast<uint4 *>(yo + off[it]) = v;
+        } else {
+#pragma unroll
+            for (int it = 0; it < OUT_IT; ++it)
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    __builtin_bit_cast(u32x4, *reinterpret_cast<const uint4 *>(s_vec + it * PIX_STEP * T::OUT_LD)), y_rsrc,
+                    voff[it], 0, 0);
         }
     } else {
+        // stride-2 form (ResNet path): only the even (row, column) pixels are kept, in a half-size map
 #pragma unroll
         for (int it = 0; it < OUT_IT; ++it) {
-            const int idx = it * T::NT + tid;
-            if (idx >= OUT_N) continue;
-            const int pix = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
-            const int gy = y0 + pix / T::TW, gx = x0 + pix % T::TW;
-            if (gy >= H || gx >= W) continue;
-            int64_t off = (((int64_t)n * H + gy) * W + gx) * a.Cout + n0 + cg * 8;
-            if (a.flags & kSubsample2) {
-                if ((gy | gx) & 1) continue;
-                off = (((int64_t)n * ((H + 1) >> 1) + (gy >> 1)) * ((W + 1) >> 1) + (gx >> 1)) * a.Cout + n0 + cg * 8;
-            }
-            *reinterpret_cast<uint4 *>(yo + off) = *reinterpret_cast<const uint4 *>(sO + pix * T::OUT_LD + cg * 8);
+            const int gy = y0 + o_ly + it * ROW_STEP;
+            if (it * T::NT + tid >= OUT_N || gy >= H || o_gx >= W || ((gy | o_gx) & 1)) continue;
+            const int64_t off =
+                (((int64_t)n * ((H + 1) >> 1) + (gy >> 1)) * ((W + 1) >> 1) + (o_gx >> 1)) * a.Cout + n0 + o_cg * 8;
+            *reinterpret_cast<uint4 *>(yo + off) = *reinterpret_cast<const uint4 *>(s_vec + it * PIX_STEP * T::OUT_LD);
         }
     }
     if (a.y_pool) {
@@ -444,12 +448,14 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
         static_assert(T::TH % 2 == 0 && T::TW % 2 == 0, "pooling windows must not straddle tiles");
         constexpr int PW = T::TW / 2, PN = (T::TH / 2) * PW;
         const int OH = (H + 1) >> 1, OW = (W + 1) >> 1;
+        auto p_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y_pool + (int64_t)n * OH * OW * a.Cout, 0, OH * OW * a.Cout * 2,
+                                                        0x00020000);
         for (int idx = tid; idx < PN * VEC_PER_PIX; idx += T::NT) {
             const int pp = idx / VEC_PER_PIX, cg = idx % VEC_PER_PIX;
             const int py = pp / PW, px = pp % PW;
             const int oy = (y0 >> 1) + py, ox = (x0 >> 1) + px;
             if (oy >= OH || ox >= OW) continue;
-            uint16_t *dst = a.y_pool + (((int64_t)n * OH + oy) * OW + ox) * a.Cout + n0 + cg * 8;
+            const int poff = ((oy * OW + ox) * a.Cout + n0 + cg * 8) * 2;
             if (a.flags & FOSVOS_CONV_RELU) {  // the staged values are >= 0: the maximum is an integer max on the packed pairs
                 uint4 mx = make_uint4(0, 0, 0, 0);
 #pragma unroll
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
                     if (y0 + ly < H && x0 + lx < W)
                         mx = max_nonneg_bf16x8(mx, *reinterpret_cast<const uint4 *>(sO + (ly * T::TW + lx) * T::OUT_LD + cg * 8));
                 }
-                *reinterpret_cast<uint4 *>(dst) = mx;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mx), p_rsrc, poff, 0, 0);
                 continue;
             }
             float m[8];
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
                     for (int j = 0; j < 8; ++j) m[j] = f[j] > m[j] ? f[j] : m[j];
                 }
             }
-            *reinterpret_cast<uint4 *>(dst) = pack8(m);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pack8(m)), p_rsrc, poff, 0, 0);
         }
     }
     FOSVOS_STAMP_AT(10)
@@ -707,8 +713,9 @@ int check_common(const void *x, const void *w, const void *y, int N, int H, int 
     FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && in_ch > 0 && out_ch > 0, FOSVOS_E_SHAPE, "%s: bad shape N=%d H=%d W=%d in=%d out=%d",
                    who, N, H, W, in_ch, out_ch);
     FOSVOS_REQUIRE(out_ch % 16 == 0, FOSVOS_E_SHAPE, "%s: output channels %d not a multiple of 16", who, out_ch);
-    FOSVOS_REQUIRE((int64_t)H * W * roundup(in_ch, 32) < 0x7fffffffLL && (int64_t)H * W * out_ch < 0x7fffffffLL,
-                   FOSVOS_E_SHAPE, "%s: one image exceeds 2^31 elements", who);
+    // (the kernels address one image with 32-bit BYTE offsets through a buffer descriptor)
+    FOSVOS_REQUIRE((int64_t)H * W * roundup(in_ch, 32) * 2 < 0x7fffffffLL && (int64_t)H * W * out_ch * 4 < 0x7fffffffLL,
+                   FOSVOS_E_SHAPE, "%s: one image exceeds 2^31 bytes", who);
     return FOSVOS_OK;
 }
 }  // namespace
