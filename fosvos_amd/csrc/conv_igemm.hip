@@ -343,25 +343,6 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
         }
         return;
     }
-    __syncthreads();  // every wave is done with sA/sB: reuse the memory as the bf16 output tile
-    uint16_t *sO = reinterpret_cast<uint16_t *>(smem);
-#pragma unroll
-    for (int j = 0; j < T::NF; ++j) {
-        const int col = wn * T::WAVE_N + j * 16 + q * 4;
-        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) b = *reinterpret_cast<const float4 *>(a.bias + n0 + col);
-#pragma unroll
-        for (int i = 0; i < T::MF; ++i) {
-            const int pix = wm * T::WAVE_M + i * 16 + cl;
-            float v0 = acc[i][j][0] + b.x, v1 = acc[i][j][1] + b.y, v2 = acc[i][j][2] + b.z, v3 = acc[i][j][3] + b.w;
-            if (a.flags & FOSVOS_CONV_RELU) {
-                v0 = relu_f(v0); v1 = relu_f(v1); v2 = relu_f(v2); v3 = relu_f(v3);
-            }
-            *reinterpret_cast<uint2 *>(sO + pix * T::OUT_LD + col) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
-        }
-    }
-    __syncthreads();
-    FOSVOS_STAMP_AT(9)
     constexpr int VEC_PER_PIX = T::BN / 8;
     constexpr int OUT_N = T::BM * VEC_PER_PIX;      // 16-byte output vectors of the tile
     constexpr int OUT_IT = (OUT_N + T::NT - 1) / T::NT;  // ... per thread
@@ -376,33 +357,61 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
     const int o_ly = o_pix / T::TW, o_gx = x0 + o_pix % T::TW;
     const int img_bytes = H * W * a.Cout * 2;
     uint16_t *yo = reinterpret_cast<uint16_t *>(a.y);
-    const uint16_t *s_vec = sO + o_pix * T::OUT_LD + o_cg * 8;  // this thread's first staged vector; the next is PIX_STEP rows of sO on
-    if (!(a.flags & kSubsample2)) {
-        int voff[OUT_IT];
+    // Everything the epilogue reads from memory is requested HERE, in front of the barrier and the staging of the tile:
+    // the dgrad operands (ReLU mask of the producing layer, the other consumer's gradient: all of a thread's vectors at
+    // once) and the bias.  Loaded where they are used, each was an exposed round trip per tile (the bias: one per 16 channels).
+    int voff[OUT_IT];
 #pragma unroll
-        for (int it = 0; it < OUT_IT; ++it) {
-            const int gy = y0 + o_ly + it * ROW_STEP;
-            const bool ok = it * T::NT + tid < OUT_N && gy < H && o_gx < W;
-            voff[it] = ok ? ((gy * W + o_gx) * a.Cout + n0 + o_cg * 8) * 2 : -1;
+    for (int it = 0; it < OUT_IT; ++it) {
+        const int gy = y0 + o_ly + it * ROW_STEP;
+        const bool ok = it * T::NT + tid < OUT_N && gy < H && o_gx < W;
+        voff[it] = ok ? ((gy * W + o_gx) * a.Cout + n0 + o_cg * 8) * 2 : -1;
+    }
+    const bool masked = (a.relu_src || a.addend) && !(a.flags & kSubsample2);
+    uint4 mk[OUT_IT], ad[OUT_IT];
+#pragma unroll
+    for (int it = 0; it < OUT_IT; ++it) mk[it] = ad[it] = make_uint4(0, 0, 0, 0);
+    if (masked) {
+        auto m_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t *>(a.relu_src ? a.relu_src + (int64_t)n * H * W * a.Cout : yo), 0,
+            a.relu_src ? img_bytes : 0, 0x00020000);
+        auto ad_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t *>(a.addend ? a.addend + (int64_t)n * H * W * a.Cout : yo), 0,
+            a.addend ? img_bytes : 0, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < OUT_IT; ++it)
+            mk[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(m_rsrc, voff[it], 0, 0));
+#pragma unroll
+        for (int it = 0; it < OUT_IT; ++it)
+            ad[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ad_rsrc, voff[it], 0, 0));
+    }
+    float4 bias_r[T::NF];
+#pragma unroll
+    for (int j = 0; j < T::NF; ++j)
+        bias_r[j] = a.bias ? *reinterpret_cast<const float4 *>(a.bias + n0 + wn * T::WAVE_N + j * 16 + q * 4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();  // every wave is done with sA/sB: reuse the memory as the bf16 output tile
+    uint16_t *sO = reinterpret_cast<uint16_t *>(smem);
+#pragma unroll
+    for (int j = 0; j < T::NF; ++j) {
+        const int col = wn * T::WAVE_N + j * 16 + q * 4;
+        const float4 b = bias_r[j];
+#pragma unroll
+        for (int i = 0; i < T::MF; ++i) {
+            const int pix = wm * T::WAVE_M + i * 16 + cl;
+            float v0 = acc[i][j][0] + b.x, v1 = acc[i][j][1] + b.y, v2 = acc[i][j][2] + b.z, v3 = acc[i][j][3] + b.w;
+            if (a.flags & FOSVOS_CONV_RELU) {
+                v0 = relu_f(v0); v1 = relu_f(v1); v2 = relu_f(v2); v3 = relu_f(v3);
+            }
+            *reinterpret_cast<uint2 *>(sO + pix * T::OUT_LD + col) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
         }
-        auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(yo + (int64_t)n * H * W * a.Cout, 0, img_bytes, 0x00020000);
-        if (a.relu_src || a.addend) {
-            // dgrad: ReLU mask of the producing layer and the other consumer's gradient.  ALL of a thread's mask / addend
-            // vectors are requested before the first one is used: rolled, this loop waited out one full memory latency per
-            // vector and operand (8 x 2 round trips per workgroup).
-            uint4 mk[OUT_IT], ad[OUT_IT];
-            auto m_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<uint16_t *>(a.relu_src ? a.relu_src + (int64_t)n * H * W * a.Cout : yo), 0,
-                a.relu_src ? img_bytes : 0, 0x00020000);
-            auto ad_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<uint16_t *>(a.addend ? a.addend + (int64_t)n * H * W * a.Cout : yo), 0,
-                a.addend ? img_bytes : 0, 0x00020000);
-#pragma unroll
-            for (int it = 0; it < OUT_IT; ++it)
-                mk[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(m_rsrc, voff[it], 0, 0));
-#pragma unroll
-            for (int it = 0; it < OUT_IT; ++it)
-                ad[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ad_rsrc, voff[it], 0, 0));
+    }
+    __syncthreads();
+    FOSVOS_STAMP_AT(9)
+    const uint16_t *s_vec = sO + o_pix * T::OUT_LD + o_cg * 8;  // this thread's first staged vector; the next is PIX_STEP rows of sO on
+    auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(yo + (int64_t)n * H * W * a.Cout, 0, img_bytes, 0x00020000);
+    if (!(a.flags & kSubsample2)) {
+        if (masked) {
 #pragma unroll
             for (int it = 0; it < OUT_IT; ++it) {
                 uint4 v = *reinterpret_cast<const uint4 *>(s_vec + it * PIX_STEP * T::OUT_LD);
