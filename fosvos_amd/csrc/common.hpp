@@ -115,6 +115,16 @@ __device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even, N
     return __builtin_bit_cast(uint16_t, b);
 }
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// eight fp32 values that ARE bf16 values (low 16 mantissa bits zero: unpacked bf16, or zero) back into packed pairs:
+// one byte permute per pair, no rounding involved
+__device__ __forceinline__ uint4 repack8(const float (&f)[8]) {
+    uint4 v;
+    v.x = __builtin_amdgcn_perm(__float_as_uint(f[1]), __float_as_uint(f[0]), 0x07060302u);
+    v.y = __builtin_amdgcn_perm(__float_as_uint(f[3]), __float_as_uint(f[2]), 0x07060302u);
+    v.z = __builtin_amdgcn_perm(__float_as_uint(f[5]), __float_as_uint(f[4]), 0x07060302u);
+    v.w = __builtin_amdgcn_perm(__float_as_uint(f[7]), __float_as_uint(f[6]), 0x07060302u);
+    return v;
+}
 // two floats -> two bf16 in one register: ONE v_cvt_pk_bf16_f32 (the scalar form costs two converts + shift + or)
 typedef float fosvos_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 fosvos_bf16x2 __attribute__((ext_vector_type(2)));
