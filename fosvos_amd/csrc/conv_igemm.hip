@@ -575,6 +575,7 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int64
 // (Tile<16, 32, 64, 8, 1>, 512 px x 64 ch on eight waves, loads a chunk's weight tile once per 512 pixels: -35 % staging bytes,
 // and 5-15 % SLOWER on every layer at three frames per launch (895 vs 966 frames/s on the step): the template takes it as is)
 using TileBig = Tile<8, 32, 64, 4, 1>;    // 256 px x 64 ch
+using TileSquare = Tile<16, 16, 64, 4, 1>; // 256 px x 64 ch as 16 x 16: the same kernel where 8 x 32 tiles overhang the map more
 using TileMid = Tile<8, 16, 64, 2, 2>;    // 128 px x 64 ch
 using TileSmall = Tile<4, 16, 64, 2, 2>;  //  64 px x 64 ch
 using TileSide = Tile<8, 32, 16, 4, 1>;   // 256 px x 16 ch: side_prep at large maps
@@ -582,7 +583,7 @@ using TileSideS = Tile<4, 16, 16, 4, 1>;  //  64 px x 16 ch: side_prep at small 
 using TileHalf = Tile<8, 32, 32, 4, 1>;   // 256 px x 32 ch: the 32-channel layers of the thinned ResNets
 using TileHalfS = Tile<4, 16, 32, 4, 1>;  //  64 px x 32 ch: ... at small maps
 
-enum TileId { kBig, kMid, kSmall, kSide, kSideS, kHalf, kHalfS };
+enum TileId { kBig, kMid, kSmall, kSide, kSideS, kHalf, kHalfS, kSquare };
 
 struct ConvPlan {
     TileId tile;
@@ -605,8 +606,14 @@ ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
         // 256-pixel tiles as soon as there is one per CU (measured: 420 workgroups of 8x32 beat 840 of 8x16 by 8 % at
         // 120x214x256 alone; at 60x107x512, 256 of them beat 448 of 8x16 by 1 % of the whole step beside the wgrad
         // stream, which fills the second slot of each CU); below that the 128-pixel tile, 3 per CU
-        if (blocks(8, 32, 64) >= kMinBlocks / 2) { p.tile = kBig; nb = blocks(8, 32, 64); }
-        else { p.tile = kMid; nb = blocks(8, 16, 64); }
+        if (blocks(8, 32, 64) >= kMinBlocks / 2) {
+            // ... as 8 x 32 or as 16 x 16 pixels, whichever overhangs the map less (a tile computes all of its 256 pixels:
+            // 60 x 107 is 64 x 128 = 8192 pixels of work in 8 x 32 tiles, 64 x 112 = 7168 in 16 x 16 ones)
+            const int64_t area_wide = cdiv(H, 8) * 8 * cdiv(W, 32) * 32, area_sq = cdiv(H, 16) * 16 * cdiv(W, 16) * 16;
+            static const bool allow_sq = !(getenv("FOSVOS_NO_SQUARE_TILE") && atoi(getenv("FOSVOS_NO_SQUARE_TILE")));
+            if (allow_sq && area_sq < area_wide) { p.tile = kSquare; nb = blocks(16, 16, 64); }
+            else { p.tile = kBig; nb = blocks(8, 32, 64); }
+        } else { p.tile = kMid; nb = blocks(8, 16, 64); }
     } else if (out_ch == 32) {
         if (pixels >= 256 * 256) { p.tile = kHalf; nb = blocks(8, 32, 32); }
         else { p.tile = kHalfS; nb = blocks(4, 16, 32); }
@@ -615,10 +622,12 @@ ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
         else { p.tile = kSideS; nb = blocks(4, 16, 16); }
     }
     if (out_ch % 64 == 0) {
-        static const char *force = getenv("FOSVOS_FORCE_TILE");  // lab switch: 0 = 8x32, 1 = 8x16, 2 = 4x16 pixel tiles
-        if (force && atoi(force) >= 0 && atoi(force) <= 2) {
+        // lab switch: 0 = 8x32, 1 = 8x16, 2 = 4x16 pixel tiles of 64 channels; 5 = 8x32 pixels x 32 channels
+        static const char *force = getenv("FOSVOS_FORCE_TILE");
+        if (force && ((atoi(force) >= 0 && atoi(force) <= 2) || atoi(force) == (int)kHalf)) {
             p.tile = (TileId)atoi(force);
-            nb = p.tile == kBig ? blocks(8, 32, 64) : p.tile == kMid ? blocks(8, 16, 64) : blocks(4, 16, 64);
+            nb = p.tile == kBig ? blocks(8, 32, 64) : p.tile == kMid ? blocks(8, 16, 64)
+                 : p.tile == kHalf ? blocks(8, 32, 32) : blocks(4, 16, 64);
         }
     }
     int ks = 1;
@@ -706,6 +715,7 @@ int dispatch(ConvArgs a, int in_ch, void *workspace, size_t workspace_bytes, hip
     }
     switch (plan.tile) {
         case kBig: return launch<TileBig, false>(a, plan, st, in_ch);
+        case kSquare: return launch<TileSquare, false>(a, plan, st, in_ch);
         case kMid: return launch<TileMid, false>(a, plan, st, in_ch);
         case kSmall: return launch<TileSmall, false>(a, plan, st, in_ch);
         case kSide: return f32 ? launch<TileSide, true>(a, plan, st, in_ch) : launch<TileSide, false>(a, plan, st, in_ch);

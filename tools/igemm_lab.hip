@@ -62,7 +62,7 @@ int main(int argc, char **argv) {
     void *ws = nullptr;
     if (wsb) CK(hipMalloc(&ws, wsb));
     const ConvPlan plan = make_plan(1, H, W, Ci, Co);
-    const int th = plan.tile == kSmall ? 4 : 8, tw = plan.tile == kBig ? 32 : 16;
+    const int th = plan.tile == kSmall ? 4 : plan.tile == kSquare ? 16 : 8, tw = plan.tile == kBig ? 32 : 16;
     const int64_t nwg = cdiv(W, tw) * cdiv(H, th) * (Co / 64) * plan.k_splits;
     printf("conv %dx%d Ci=%d Co=%d  tile=%d k_splits=%d  workgroups=%lld\n", H, W, Ci, Co, (int)plan.tile,
            plan.k_splits, (long long)nwg);
