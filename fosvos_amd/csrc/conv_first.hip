@@ -1,118 +1,180 @@
-// conv1_1 forward: Conv2d(3 -> Co, 3x3, pad 1) + bias + ReLU straight from the fp32 NCHW frame
+// conv1_1 forward: Conv2d(3 -> 64, 3x3, pad 1) + bias + ReLU straight from the fp32 NCHW frame
 // (reference: stages[0][0..1], src/networks/osvos_vgg.py:92-93).
 //
-// K = 27 is far too small for MFMA to pay in the forward direction: fp32 VALU, bandwidth-leaning (reads
-// 12 B/pixel of frame, writes 2*Co B/pixel of bf16 NHWC activation).  Its weight gradient reduces over 410 k
-// pixels and lives in conv_wgrad.hip (MFMA, 16-channel padded image).  No dgrad: the image needs none.
+// The layer is 0.7 GMAC per 480x854 frame and writes 52 MB of bf16 NHWC activation: HBM-write-bound if the arithmetic
+// is cheap.  On the vector ALU it is not (round 1's kernel: 864 FMAs per lane and 32-pixel segment, 45 % of the fp32 VALU
+// rate, 23 us per frame, and every one of those instructions competes with the MFMA waves of the other stream), so the
+// arithmetic runs on the matrix pipe without giving up fp32 inputs: frame and weights are each split into two bf16 terms
+// (x = xh + xl, xh = bf16(x), xl = bf16(x - xh); likewise w) and a product is the sum of the four term products,
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16 - what is lost is the second rounding of the low terms, ~2^-18 relative
+// (a plain bf16 frame, 2^-9, shifts the logits measurably: DESIGN.md section 4).
+//
+// GEMM view per 16 pixels: out[64 co][16 px] = W[64][K] * X[K][16], K = (ky, kx, ci) laid out so that the operand of a
+// lane is 16 contiguous bytes of the staged tile: a halo row is stored pixel-major with 4 channels per pixel (3 real + a
+// zero), 8 bytes per pixel and term; k-block b, lane group kg, element e <-> ky = 2 b + (kg >> 1), kx = 2 (kg & 1) + (e >> 2),
+// ci = e & 3.  ky = 3, kx = 3 and ci = 3 are padding of K: their WEIGHTS are zero, the data read there is finite
+// (a neighbouring pixel, a zeroed pad column or the zero channel).  Two k-blocks of 32 cover the 27 taps.
+// The weight rows are permuted so that a lane ends up with 16 CONSECUTIVE output channels of its pixel (row r of
+// co-block j is channel 16 (r >> 2) + 4 j + (r & 3)): two 16-byte stores per lane and pixel.
+//
+// Its weight gradient reduces over 410 k pixels and lives in conv_wgrad_first.hip.  No dgrad: the image needs none.
 #include "common.hpp"
 
 using namespace fosvos;
 
 namespace {
-constexpr int CO = 64;     // the only instantiation the model needs (checked at the entry point)
-constexpr int PX = 4;      // consecutive pixels per thread
-constexpr int TW = 8 * PX; // pixels per wave (one image-row segment)
-constexpr int ROWS = 4;    // waves per block = image rows per block
+constexpr int CO = 64;              // the only instantiation the model needs (checked at the entry point)
+constexpr int TH = 8, TW = 32;      // output pixels of a tile: 4 waves x 2 rows x 2 steps of 16 pixels
+constexpr int HR = TH + 2;          // halo rows
+constexpr int HC = TW + 4;          // halo columns: 34 real + 2 zero columns the kx = 3 padding taps may read
+constexpr int IMG = HR * HC;        // staged pixels per tile
+constexpr int IMG_BYTES = IMG * 8;  // ... of one term (hi or lo): 4 bf16 per pixel
+constexpr int BUF_BYTES = 2 * IMG_BYTES;
+constexpr int S_IT = (IMG + 255) / 256;  // staged pixels per thread
 
-// ---------------------------------------------------------------------------------------- forward
-// Block = 4 waves = 4 image rows x 32 pixels.  Lane l of a wave owns pixels 4*(l/8)..+3 of the
-// segment and output channels 8*(l%8)..+7, so the 8 lanes of a pixel store one full 128-byte
-// NHWC pixel.  Weights live in LDS as [27][64] fp32 (each lane reads its 8 channels as 2 x 16 B:
-// the 8 channel groups cover one 256-byte bank row, conflict-free); the 6 x 66 input halo rows
-// per channel live in LDS too and are read as broadcasts within a pixel group.
+struct Split {
+    uint16_t hi, lo;
+};
+struct alignas(16) Pair8 {  // two 8-byte halves of one 16-byte MFMA operand
+    uint2 a, b;
+};
+__device__ __forceinline__ Split split_bf16(float v) {
+    const uint16_t h = f2bf(v);
+    return Split{h, f2bf(v - bf2f(h))};
+}
+
 __global__ __launch_bounds__(256) void k_first_fwd(const float *__restrict__ frame, const float *__restrict__ w,
-                                                    const float *__restrict__ bias, uint16_t *__restrict__ y, int H,
-                                                    int W) {
-    __shared__ __attribute__((aligned(16))) float s_w[27][CO];
-    __shared__ __attribute__((aligned(16))) float s_in[3][ROWS + 2][TW + 8];  // x index 0 <-> image x0-4 (16-B aligned)
-    const int n = blockIdx.z;
-    const int y0 = blockIdx.y * ROWS;
-    const int x0 = blockIdx.x * TW;
-    const int tid = threadIdx.x;
-    // staging: all of a thread's global loads are issued before its first LDS store (unconditional loads from
-    // clamped addresses); rolled, each element waited out its own memory round trip (7 + 3 in a row per thread)
-    {
-        constexpr int WN = 27 * CO, WIT = (WN + 255) / 256, IN = 3 * (ROWS + 2) * (TW + 8), IIT = (IN + 255) / 256;
-        float tw[WIT], ti[IIT];
-        bool oki[IIT];
-        const int64_t plane = (int64_t)H * W;
-#pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-            const int i = min(it * 256 + tid, WN - 1);
-            tw[it] = w[(i % CO) * 27 + i / CO];  // s_w[k = ci*9 + tap][co]
-        }
-#pragma unroll
-        for (int it = 0; it < IIT; ++it) {
-            const int i = min(it * 256 + tid, IN - 1);
-            const int xx = i % (TW + 8);
-            const int r = (i / (TW + 8)) % (ROWS + 2);
-            const int c = i / ((TW + 8) * (ROWS + 2));
-            const int gy = y0 + r - 1, gx = x0 + xx - 4;
-            oki[it] = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            ti[it] = frame[((int64_t)n * 3 + c) * plane + (int64_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)];
-        }
-#pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-            const int i = it * 256 + tid;
-            if (i < WN) s_w[i / CO][i % CO] = tw[it];
-        }
-#pragma unroll
-        for (int it = 0; it < IIT; ++it) {
-            const int i = it * 256 + tid;
-            if (i < IN) (&s_in[0][0][0])[i] = oki[it] ? ti[it] : 0.f;
-        }
-    }
+                                                    const float *__restrict__ bias, uint16_t *__restrict__ y, int N,
+                                                    int H, int W, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) char s_x[2 * BUF_BYTES];  // two tiles (double buffer) x {hi, lo} images
+    __shared__ float s_w[CO * 27];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, kg = lane >> 4;
+    const int n_tiles = tiles_x * tiles_y * N;
+    const int64_t plane = (int64_t)H * W;
+
+    // ---- weights -> the MFMA row operands of this lane, both terms, kept in registers for every tile of the workgroup
+    for (int i = tid; i < CO * 27; i += 256) s_w[i] = w[i];
     __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    const int pg = lane >> 3, cg = lane & 7;
-    const int gy = y0 + wave;
-    if (gy >= H) return;
-    float acc[PX][8];
-    {
-        const float4 b0 = *reinterpret_cast<const float4 *>(bias + cg * 8);
-        const float4 b1 = *reinterpret_cast<const float4 *>(bias + cg * 8 + 4);
+    bf16x8 wh[2][4], wl[2][4];
 #pragma unroll
-        for (int p = 0; p < PX; ++p) {
-            acc[p][0] = b0.x; acc[p][1] = b0.y; acc[p][2] = b0.z; acc[p][3] = b0.w;
-            acc[p][4] = b1.x; acc[p][5] = b1.y; acc[p][6] = b1.z; acc[p][7] = b1.w;
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = 16 * (p >> 2) + 4 * j + (p & 3);  // MFMA row p of co-block j
+            uint16_t hv[8], lv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ky = 2 * b + (kg >> 1), kx = 2 * (kg & 1) + (e >> 2), ci = e & 3;
+                float v = 0.f;
+                if (ky < 3 && kx < 3 && ci < 3) v = s_w[ch * 27 + ci * 9 + ky * 3 + kx];
+                const Split s = split_bf16(v);
+                hv[e] = s.hi;
+                lv[e] = s.lo;
+            }
+            const Pair8 hh{make_uint2(hv[0] | ((uint32_t)hv[1] << 16), hv[2] | ((uint32_t)hv[3] << 16)),
+                           make_uint2(hv[4] | ((uint32_t)hv[5] << 16), hv[6] | ((uint32_t)hv[7] << 16))};
+            const Pair8 ll{make_uint2(lv[0] | ((uint32_t)lv[1] << 16), lv[2] | ((uint32_t)lv[3] << 16)),
+                           make_uint2(lv[4] | ((uint32_t)lv[5] << 16), lv[6] | ((uint32_t)lv[7] << 16))};
+            wh[b][j] = __builtin_bit_cast(bf16x8, hh);
+            wl[b][j] = __builtin_bit_cast(bf16x8, ll);
         }
-    }
-    // the (c, ky) loops stay rolled: fully unrolled, hipcc hoists all 27 weight rows and every input row into
-    // registers (256 VGPRs + AGPR spills, one wave per SIMD)
-#pragma unroll 1
-    for (int c = 0; c < 3; ++c) {
-#pragma unroll 1
-        for (int ky = 0; ky < 3; ++ky) {
-            // inputs x = 4*pg-1 .. 4*pg+4 of halo row (wave + ky): LDS x index = 4*pg + 3 .. 4*pg + 8
-            float in[PX + 2];
-            const float *row = &s_in[c][wave + ky][pg * 4];
-            const float4 a = *reinterpret_cast<const float4 *>(row);       // idx 0..3
-            const float4 b = *reinterpret_cast<const float4 *>(row + 4);   // idx 4..7
-            const float e = row[8];
-            in[0] = a.w; in[1] = b.x; in[2] = b.y; in[3] = b.z; in[4] = b.w; in[5] = e;
+    // bias of this lane's 16 output channels
+    float4 bv[4];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int k = c * 9 + ky * 3 + kx;
-                const float4 w0 = *reinterpret_cast<const float4 *>(&s_w[k][cg * 8]);
-                const float4 w1 = *reinterpret_cast<const float4 *>(&s_w[k][cg * 8 + 4]);
+    for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const float4 *>(bias + 16 * kg + 4 * j);
+
+    // ---- staging: thread t owns staged pixels t, t + 256 of a tile (row-major over HR x HC)
+    float st[S_IT][3];
+    auto load_tile = [&](int tile) {
+        const int tx = tile % tiles_x, r = tile / tiles_x;
+        const int ty = r % tiles_y, n = r / tiles_y;
+        const float *fn = frame + (int64_t)n * 3 * plane;
 #pragma unroll
-                for (int p = 0; p < PX; ++p) {
-                    const float v = in[p + kx];
-                    acc[p][0] += v * w0.x; acc[p][1] += v * w0.y; acc[p][2] += v * w0.z; acc[p][3] += v * w0.w;
-                    acc[p][4] += v * w1.x; acc[p][5] += v * w1.y; acc[p][6] += v * w1.z; acc[p][7] += v * w1.w;
-                }
+        for (int it = 0; it < S_IT; ++it) {
+            const int idx = it * 256 + tid;
+            const int hy = idx / HC, hx = idx - hy * HC;
+            const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1;
+            const bool ok = idx < IMG && hx < TW + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int64_t off = ok ? (int64_t)gy * W + gx : 0;  // unconditional loads from a valid address, masked below
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = fn[c * plane + off];
+                st[it][c] = ok ? v : 0.f;
             }
         }
-    }
+    };
+    auto store_tile = [&](char *buf) {
 #pragma unroll
-    for (int p = 0; p < PX; ++p) {
-        const int gx = x0 + pg * PX + p;
-        if (gx < W) {
-            float o[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = relu_f(acc[p][j]);
-            *reinterpret_cast<uint4 *>(y + (((int64_t)n * H + gy) * W + gx) * CO + cg * 8) = pack8(o);
+        for (int it = 0; it < S_IT; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx < IMG) {
+                const Split a = split_bf16(st[it][0]), b = split_bf16(st[it][1]), c = split_bf16(st[it][2]);
+                *reinterpret_cast<uint2 *>(buf + idx * 8) = make_uint2(a.hi | ((uint32_t)b.hi << 16), c.hi);
+                *reinterpret_cast<uint2 *>(buf + IMG_BYTES + idx * 8) = make_uint2(a.lo | ((uint32_t)b.lo << 16), c.lo);
+            }
         }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < n_tiles) {
+        load_tile(tile);
+        store_tile(s_x);
+    }
+    __syncthreads();
+    for (int it_tile = 0; tile < n_tiles; tile += gridDim.x, ++it_tile) {
+        const char *cur = s_x + (it_tile & 1) * BUF_BYTES;
+        char *nxt = s_x + ((it_tile & 1) ^ 1) * BUF_BYTES;
+        const int next = tile + (int)gridDim.x;
+        if (next < n_tiles) load_tile(next);  // in flight under this tile's matrix work
+
+        const int tx = tile % tiles_x, r = tile / tiles_x;
+        const int ty = r % tiles_y, n = r / tiles_y;
+        // operand address of this lane inside a halo row: pixel p + 2 (kg & 1) of the step, rows ky = kg >> 1 (k-block 0)
+        // and 2 (k-block 1; its upper lane groups are all padding and re-read row 2)
+        const int lane_px = (p + 2 * (kg & 1)) * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = 2 * wave + (s >> 1), xb = (s & 1) * 16;
+            const int gy = ty * TH + row, gx = tx * TW + xb + p;
+            f32x4 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = f32x4{bv[j].x, bv[j].y, bv[j].z, bv[j].w};
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int hy = row + (b == 0 ? (kg >> 1) : 2);
+                const char *src = cur + (hy * HC + xb) * 8 + lane_px;
+                // 16 bytes at an 8-byte-aligned address: two 8-byte LDS reads (one ds_read2_b64) per term
+                const Pair8 h{*reinterpret_cast<const uint2 *>(src), *reinterpret_cast<const uint2 *>(src + 8)};
+                const Pair8 l{*reinterpret_cast<const uint2 *>(src + IMG_BYTES),
+                              *reinterpret_cast<const uint2 *>(src + IMG_BYTES + 8)};
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, h), xl = __builtin_bit_cast(bf16x8, l);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[b][j], xl, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[b][j], xh, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[b][j], xl, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[b][j], xh, acc[j], 0, 0, 0);
+                }
+            }
+            // acc[j][i] = channel 16 kg + 4 j + i of pixel p: ReLU, pack, 32 contiguous bytes per lane
+            if (gy < H && gx < W) {
+                uint4 o0, o1;
+                o0.x = pack2bf(relu_f(acc[0][0]), relu_f(acc[0][1]));
+                o0.y = pack2bf(relu_f(acc[0][2]), relu_f(acc[0][3]));
+                o0.z = pack2bf(relu_f(acc[1][0]), relu_f(acc[1][1]));
+                o0.w = pack2bf(relu_f(acc[1][2]), relu_f(acc[1][3]));
+                o1.x = pack2bf(relu_f(acc[2][0]), relu_f(acc[2][1]));
+                o1.y = pack2bf(relu_f(acc[2][2]), relu_f(acc[2][3]));
+                o1.z = pack2bf(relu_f(acc[3][0]), relu_f(acc[3][1]));
+                o1.w = pack2bf(relu_f(acc[3][2]), relu_f(acc[3][3]));
+                uint16_t *dst = y + (((int64_t)n * H + gy) * W + gx) * CO + 16 * kg;
+                *reinterpret_cast<uint4 *>(dst) = o0;
+                *reinterpret_cast<uint4 *>(dst + 8) = o1;
+            }
+        }
+        if (next < n_tiles) store_tile(nxt);  // image `nxt` was last read in the previous iteration (barrier below)
+        __syncthreads();
     }
 }
 
@@ -125,10 +187,14 @@ extern "C" int fosvos_conv3x3_first_fwd(const float *frame, const float *w, cons
     FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && N <= 65535, FOSVOS_E_SHAPE, "conv3x3_first_fwd: bad shape N=%d H=%d W=%d",
                    N, H, W);
     FOSVOS_ENTER(device);
-    dim3 grid((unsigned)cdiv(W, TW), (unsigned)cdiv(H, ROWS), (unsigned)N);
+    const int tiles_x = (int)cdiv(W, TW), tiles_y = (int)cdiv(H, TH);
+    const int64_t tiles = (int64_t)tiles_x * tiles_y * N;
+    FOSVOS_REQUIRE(tiles < 0x7fffffffLL, FOSVOS_E_SHAPE, "conv3x3_first_fwd: too many tiles");
+    // persistent workgroups (the weight operands are built once per workgroup): four per CU
+    const unsigned grid = (unsigned)std::min<int64_t>(tiles, 1024);
     FOSVOS_PROF("k_first_fwd", stream, 2.0 * N * H * W * 27 * Co);
-    hipLaunchKernelGGL(k_first_fwd, grid, dim3(256), 0, (hipStream_t)stream, frame, w, bias, y, H, W);
+    hipLaunchKernelGGL(k_first_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, frame, w, bias, y, N, H, W, tiles_x,
+                       tiles_y);
     FOSVOS_LAUNCH_CHECK();
     return FOSVOS_OK;
 }
-

@@ -23,11 +23,14 @@ class FusedSGD(optim.SGD):
         kw.pop("fused", None)
         super().__init__(params, lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
                          nesterov=nesterov, **kw)
-        self._host_table = None
-        self._dev_table = None
+        self._tables = {}  # tag -> the parameter table of that subset: entries, pinned staging copy, device copy, upload event
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, only=None, tag="all"):
+        """``only``: restrict this call to these parameters (an extension for loops that step parts of the model as soon as
+        their gradients are final; every parameter must still be stepped exactly once per optimizer step by the caller).
+        ``tag`` names the subset: the device-side table of a subset is kept under its tag and re-sent only when it changes."""
+        only_ids = None if only is None else {id(p) for p in only}
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -47,7 +50,7 @@ class FusedSGD(optim.SGD):
             elif m != momentum:
                 raise NotImplementedError("FusedSGD: one momentum value for all groups (as in the reference recipe)")
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or (only_ids is not None and id(p) not in only_ids):
                     continue
                 if not p.is_cuda:
                     raise RuntimeError("FusedSGD: parameters must live on the GPU (no CPU fallback)")
@@ -76,21 +79,22 @@ class FusedSGD(optim.SGD):
         # The device-side table only changes when a pointer, a size or a group's lr / weight decay does (the online loop:
         # never after its first step) - it is rebuilt and re-sent only then.  A rebuild rewrites the pinned staging
         # buffer, so it first waits for the previous upload to have been consumed.
-        if entries != getattr(self, "_sent_entries", None):
-            if self._host_table is None or self._host_table.numel() < nbytes:
-                self._host_table = torch.empty(max(nbytes, 4096), dtype=torch.uint8).pin_memory()
-                self._dev_table = torch.empty(max(nbytes, 4096), dtype=torch.uint8, device=device)
-            if getattr(self, "_copy_event", None) is not None:
-                self._copy_event.synchronize()
-            arr = (SgdEntry * n).from_address(self._host_table.data_ptr())
+        tab = self._tables.setdefault(tag, {"entries": None, "host": None, "dev": None, "event": None})
+        if entries != tab["entries"]:
+            if tab["host"] is None or tab["host"].numel() < nbytes:
+                tab["host"] = torch.empty(max(nbytes, 4096), dtype=torch.uint8).pin_memory()
+                tab["dev"] = torch.empty(max(nbytes, 4096), dtype=torch.uint8, device=device)
+            if tab["event"] is not None:
+                tab["event"].synchronize()
+            arr = (SgdEntry * n).from_address(tab["host"].data_ptr())
             for i, e in enumerate(entries):
                 arr[i].param, arr[i].grad, arr[i].momentum_buf, arr[i].numel, arr[i].lr, arr[i].weight_decay = e
-            self._dev_table[:nbytes].copy_(self._host_table[:nbytes], non_blocking=True)
-            self._copy_event = torch.cuda.Event()
-            self._copy_event.record()
-            self._sent_entries = entries
+            tab["dev"][:nbytes].copy_(tab["host"][:nbytes], non_blocking=True)
+            tab["event"] = torch.cuda.Event()
+            tab["event"].record()
+            tab["entries"] = entries
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        check(lib().fosvos_sgd_momentum_step(self._dev_table.data_ptr(), n, max_numel, momentum, 0, idx,
+        check(lib().fosvos_sgd_momentum_step(tab["dev"].data_ptr(), n, max_numel, momentum, 0, idx,
                                              torch.cuda.current_stream(idx).cuda_stream), "sgd_momentum_step")
         # the kernel wrote through raw pointers: tell torch the tensors changed, so that version-keyed caches
         # (the packed bf16 weight images) and autograd's saved-tensor checks see the update

@@ -71,6 +71,18 @@ class OSVOS_VGG(nn.Module):
         return engine.run(self._packs, params, x, with_side_out=bool(getattr(self, 'compute_side_outputs', True)),
                           inplace_grad=getattr(self, 'accumulate_grads_in_place', False))
 
+    def prepack_weights(self, prefixes=None):
+        """Rebuild NOW (on the current stream) the bf16 MFMA images of the 3x3 conv weights whose fp32 masters changed since
+        they were last packed - all of them, or those whose state_dict name starts with one of `prefixes`.  `forward` does
+        this for every stale layer by itself; a loop that steps part of the model early can repack that part early too."""
+        P = dict(zip(engine.PARAM_NAMES, self._ordered_params()))
+        names = [n for n in engine.PARAM_NAMES if n.endswith(".weight") and n.startswith(("stages.", "side_prep."))
+                 and n != engine._CONV_NAMES[0][0]]  # (not conv1_1: its kernel reads the fp32 master)
+        if prefixes is not None:
+            names = [n for n in names if n.startswith(tuple(prefixes))]
+        if names:
+            self._packs.conv_many([(n, P[n]) for n in names])
+
     def join_gradients(self):
         """With ``defer_wgrad_join`` the weight-gradient kernels of a backward pass may still be running on the
         auxiliary stream when ``backward()`` returns; call this before reading ``p.grad`` (optimizer step,

@@ -113,10 +113,12 @@ class FlatGrads:
         # Trainable tensors outside every bucket form trailing buckets of their own, except those under `frozen`:
         # the engine never produces a gradient for them (the reference keeps them at lr 0), their slice stays zero.
         self.slices: List[Tuple[int, int]] = [(0, cur)]
+        self.bucket_params: List[List[torch.nn.Parameter]] = [list(self.params)]  # the parameters inside each slice
         if names is not None:
             trainable = [n for n, p in zip(names, params) if p.requires_grad]
             ends = offs[1:] + [cur]
             self.slices = []
+            self.bucket_params = []
             covered = set()
             for prefixes in buckets:
                 idx = [i for i, n in enumerate(trainable) if n.startswith(tuple(prefixes))]
@@ -125,6 +127,7 @@ class FlatGrads:
                 if idx != list(range(idx[0], idx[-1] + 1)):
                     raise ValueError(f"FlatGrads: bucket {prefixes} is not contiguous in parameter order")
                 self.slices.append((offs[idx[0]], ends[idx[-1]]))
+                self.bucket_params.append([self.params[i] for i in idx])
                 covered.update(idx)
             run: List[int] = []
             for i, n in enumerate(trainable + [None]):
@@ -132,11 +135,18 @@ class FlatGrads:
                     run.append(i)
                 elif run:
                     self.slices.append((offs[run[0]], ends[run[-1]]))
+                    self.bucket_params.append([self.params[i] for i in run])
                     run = []
         self._works: list = []
 
-    def zero(self) -> None:
-        self.flat.zero_()
+    def zero(self, buckets: Optional[Sequence[int]] = None) -> None:
+        """Zero the whole buffer, or only the slices of the given buckets."""
+        if buckets is None:
+            self.flat.zero_()
+            return
+        for b in buckets:
+            lo, hi = self.slices[b]
+            self.flat[lo:hi].zero_()
 
     def all_reduce(self, async_op: bool = False):
         """SUM of the whole buffer over ranks in one collective (no-op in a single process)."""

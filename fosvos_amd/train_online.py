@@ -120,6 +120,16 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     flat = parallel.FlatGrads([p for _, p in named], names=[n for n, _ in named])
     sync = parallel.GradSync(net, flat)
 
+    # single process on the GPU: the optimizer step is split by gradient bucket (see run_group); FOSVOS_SPLIT_STEP=0 = one step
+    early_buckets = [b for b, pre in enumerate(parallel.VGG_BUCKETS[:2]) if b < len(flat.slices)]
+    split_step = (world == 1 and flat.flat.is_cuda and hasattr(net, 'wait_grad_bucket') and len(flat.slices) > 2
+                  and hasattr(optimizer, '_tables') and os.environ.get('FOSVOS_SPLIT_STEP', '1') != '0')
+    late_buckets = [b for b in range(len(flat.slices)) if b not in early_buckets]
+    early_params = [p for b in early_buckets for p in flat.bucket_params[b]]
+    early_ids = {id(p) for p in early_params}
+    late_params = [p for group in optimizer.param_groups for p in group['params'] if id(p) not in early_ids]
+    early_prefixes = tuple(pre for b in early_buckets for pre in parallel.VGG_BUCKETS[b])
+
     n_samples = len(dataloader)
     loss_tr = []
     counter_gradient = 0
@@ -206,6 +216,8 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             net.last_pass_of_cycle = closes_cycle
         if last_of_cycle:
             sync.arm()
+        if split_step and closes_cycle:
+            net.publish_grad_buckets = True
         loss.backward(inv_avg)
         if last_of_cycle:
             sync.begin()
@@ -215,10 +227,25 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         n_iters += k
 
         if counter_gradient % local_accum == 0:
-            net.join_gradients()
-            sync.finish()  # the bucketed all-reduce begun right behind the cycle's last backward pass
-            optimizer.step()
-            flat.zero()
+            if split_step:
+                # Stages 5 and 4 hold 87 % of the parameters and their gradients are final early in the backward pass.
+                # Their share of the optimizer step, the zeroing of their gradients and the repacking of their weights are
+                # queued on the main stream right here - behind the data-gradient chain, while the weight-gradient stream
+                # is still working through stages 3-1 - and only the small rest waits for that stream.
+                net.publish_grad_buckets = False
+                for b in early_buckets:
+                    net.wait_grad_bucket(b)
+                optimizer.step(only=early_params, tag='early')
+                flat.zero(early_buckets)
+                net.prepack_weights(early_prefixes)
+                net.join_gradients()
+                optimizer.step(only=late_params, tag='late')
+                flat.zero(late_buckets)
+            else:
+                net.join_gradients()
+                sync.finish()  # the bucketed all-reduce begun right behind the cycle's last backward pass
+                optimizer.step()
+                flat.zero()
             counter_gradient = 0
 
         epoch, _idx, _mb, end_of_epoch = group[-1]
