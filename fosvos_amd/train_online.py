@@ -135,37 +135,55 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     counter_gradient = 0
     log_every = max(n_epochs // 20, 1)  # the reference divides by n_epochs // 20, which is 0 below 20 epochs
     device = next(net.parameters()).device
-    running_loss_tr = torch.zeros((), device=device)
     inv_avg = torch.ones((), device=device) / avg_grad_every_n
+    max_group = _max_group()
+    inv_avg_k = torch.full((max_group,), 1.0 / avg_grad_every_n, device=device)  # backward seed of a batched pass
 
-    pending_logs = []
+    # The reference reads loss.item() every iteration and the running loss at 20 logging points per run (device->host
+    # syncs that drain the launch queue).  Here every pass sends its per-frame losses to pinned memory with ONE asynchronous
+    # copy and the host does the bookkeeping (running sum, logging points) once the copy has landed: no device-side
+    # accumulator kernels, no sync.  `loss_tr` fills in iteration order, a few passes behind the device.
+    pending_logs = []   # (frames [(epoch, minibatch index)], host tensor with their losses, event)
+    ring, ring_free = None, []
+    if device.type == 'cuda':
+        ring = torch.empty((64, max_group), dtype=torch.float32).pin_memory()
+        ring_free = list(range(ring.shape[0]))
+    running_host = [0.0]
 
     def flush_logs(block: bool) -> None:
         while pending_logs:
-            ep, mb, host_val, landed = pending_logs[0]
+            frames, host_vals, landed, slot = pending_logs[0]
             if block:
                 landed.synchronize()
             elif not landed.query():
                 break
             pending_logs.pop(0)
-            value = float(host_val) / n_samples
-            loss_tr.append(value)
-            log.info('[Epoch {0}: {1}, numImages: {2}]'.format(seq_name, ep + 1, mb + 1))
-            log.info('Loss {0}: {1}'.format(seq_name, value))
-            summary_writer.add_scalar('data/total_loss_epoch', value, ep)
+            for i, (ep, mb) in enumerate(frames):
+                running_host[0] += float(host_vals[i])
+                if is_log_epoch(ep):
+                    value = running_host[0] / n_samples
+                    running_host[0] = 0.0
+                    loss_tr.append(value)
+                    log.info('[Epoch {0}: {1}, numImages: {2}]'.format(seq_name, ep + 1, mb + 1))
+                    log.info('Loss {0}: {1}'.format(seq_name, value))
+                    summary_writer.add_scalar('data/total_loss_epoch', value, ep)
+            if slot is not None:
+                ring_free.append(slot)
 
-    def log_point(epoch: int, minibatch_index: int) -> None:
-        # the reference reads the running loss here (a device->host sync that drains the launch queue 20 times
-        # per run); the value is copied to pinned memory asynchronously instead and logged once it has landed
-        if device.type == 'cuda':
-            host_val = torch.empty((), dtype=torch.float32, pin_memory=True)
-            host_val.copy_(running_loss_tr, non_blocking=True)
+    def record_losses(group, losses) -> None:
+        """losses: [k] detached device tensor, frame by frame in loop order."""
+        frames = [(g[0], g[1]) for g in group]
+        if ring is not None:
+            if not ring_free:
+                flush_logs(True)
+            slot = ring_free.pop()
+            host_vals = ring[slot, :len(frames)]
+            host_vals.copy_(losses, non_blocking=True)
             landed = torch.cuda.Event()
             landed.record()
         else:  # CPU tensors (the gloo tests of the data-parallel wiring): nothing to wait for
-            host_val, landed = running_loss_tr.clone(), _Landed()
-        pending_logs.append((epoch, minibatch_index, host_val, landed))
-        running_loss_tr.zero_()
+            slot, host_vals, landed = None, losses.clone(), _Landed()
+        pending_logs.append((frames, host_vals, landed, slot))
         flush_logs(False)
 
     def is_log_epoch(epoch: int) -> bool:
@@ -196,16 +214,9 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             loss = class_balanced_cross_entropy_loss(outputs[-1], gts, size_average=False)
             losses = loss.detach().reshape(1)
         else:
-            losses_k = _losses_per_frame(outputs[-1], gts)
-            loss = losses_k.sum()
-            losses = losses_k.detach()
-        if any(is_log_epoch(g[0]) for g in group):
-            for i, (epoch, minibatch_index, _mb, _end) in enumerate(group):
-                running_loss_tr.add_(losses[i])
-                if is_log_epoch(epoch):
-                    log_point(epoch, minibatch_index)
-        else:
-            running_loss_tr.add_(losses.sum() if k > 1 else losses[0])
+            loss = _losses_per_frame(outputs[-1], gts)  # [k]; the sum over frames is taken by the backward seed
+            losses = loss.detach()
+        record_losses(group, losses)
 
         # reference: `loss /= nAveGrad; loss.backward()` (src/train_online.py:92-93).  Seeding the backward pass with
         # 1/nAveGrad is the same gradient (the division's own backward produces exactly this factor) without the
@@ -218,11 +229,11 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             sync.arm()
         if split_step and closes_cycle:
             net.publish_grad_buckets = True
-        loss.backward(inv_avg)
+        loss.backward(inv_avg if k == 1 else inv_avg_k[:k])
         if last_of_cycle:
             sync.begin()
         # (the reference also sums loss.item() into a per-epoch tensorboard scalar, src/train_online.py:94-104: one
-        # device sync per frame; running_loss_tr above carries the same information without it)
+        # device sync per frame; the per-pass asynchronous copy above carries the same information without it)
         counter_gradient += k
         n_iters += k
 
