@@ -84,7 +84,9 @@ Arena make_arena(int N, int H, int W) {
 
 // ---- the library's only persistent state: timing-disabled events for the two-stream backward
 // 13 conv-output gradients + head + fork + join + d_side[0..2] (aux -> main) + 3 gradient-bucket events (19..21)
-constexpr int kNEvents = 22;
+// + "stage 2's weight gradients are queued" (22)
+constexpr int kNEvents = 23;
+constexpr int kStage2WgradEvent = 22;  // stage 2's weight-gradient kernels are queued on the wgrad stream
 constexpr int kBucketEvent0 = 19;
 struct EventPool {
     hipEvent_t ev[kNEvents];
@@ -185,6 +187,8 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
     const int acc = g->accumulate ? 1 : 0;
     WgradReduceTable reduce;  // every layer queues its slab reduction; two launches at the end run them all
     reduce.n = 0;
+    WgradReduceTable reduce_m;  // ... the reductions the MAIN stream runs behind its last data-gradient kernel (see `offload`)
+    reduce_m.n = 0;
 
     // ---- two streams: data-gradient chain on `stream`, weight gradients on `aux_stream`
     hipStream_t sm = (hipStream_t)stream;
@@ -196,6 +200,12 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
     // the weight gradients of stages 1-2 come last; after the cycle's LAST backward pass nothing runs beside them
     const bool tail = g->last_pass_of_cycle != 0;
     static const int tail_stages = getenv("FOSVOS_TAIL_STAGES") ? atoi(getenv("FOSVOS_TAIL_STAGES")) : 1;  // lab switch
+    // In the cycle's last pass the data-gradient stream runs dry while the weight-gradient stream still owes stages 2-1
+    // (timeline: ~300 us with the chip a quarter full).  Two pieces of that tail need nothing the wgrad stream has not
+    // long finished, and move to the main stream's end: conv1_1's weight gradient (its operands are the main stream's own
+    // last outputs) and the slab reduction of stage 2 (behind an event the wgrad stream records after stage 2's kernels).
+    static const bool offload_on = !(getenv("FOSVOS_TAIL_OFFLOAD") && atoi(getenv("FOSVOS_TAIL_OFFLOAD")) == 0);
+    const bool offload = tail && aux_stream != nullptr && aux_stream != stream && offload_on;
     if (par || buckets) {
         FOSVOS_ENTER(device);
         FOSVOS_TRY(get_events(device, &ev, &pool));
@@ -248,7 +258,8 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
             // side_prep[s-1]: wgrad from (stage output, d_side) on the wgrad stream; its dgrad into the stage-output
             // gradient: ReLU-masked and added to what came back through the next stage's pool (already in gact[last])
             FOSVOS_TRY(wgrad_impl(act(last), dside[s - 1], g->side_w[s - 1], g->side_b[s - 1], N, hh, ww, kStageCh[s], 16,
-                                  acc, base + a.wsa_side[s - 1], a.wsa_side_bytes[s - 1], device, sa, &reduce, tail && s <= tail_stages));
+                                  acc, base + a.wsa_side[s - 1], a.wsa_side_bytes[s - 1], device, sa,
+                                  (offload && s == 1) ? &reduce_m : &reduce, tail && s <= tail_stages));
             const uint16_t *addend = (s < 4) ? gact(last) : nullptr;
             if (par && s < 4) FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[16 + s - 1], 0));  // d_side[s-1] from the wgrad stream
             FOSVOS_TRY(fosvos_conv3x3_dgrad(dside[s - 1], w->side_wd[s - 1], act(last), addend, gact(last), N, hh, ww,
@@ -257,8 +268,12 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
         FOSVOS_TRY(publish(last));  // gradient wrt the stage output is complete
         for (int c = last; c >= first; --c) {
             if (c == 0) {
-                FOSVOS_TRY(first_wgrad_impl(frame, gact(0), g->conv_w[0], g->conv_b[0], N, H, W, kCout[0], acc,
-                                            base + a.wsa_conv[0], a.wsa_conv_bytes[0], device, sa, &reduce));
+                if (offload)  // gact(0) is the main stream's own last output: no event, and it runs beside conv1_2's
+                    FOSVOS_TRY(first_wgrad_impl(frame, gact(0), g->conv_w[0], g->conv_b[0], N, H, W, kCout[0], acc,
+                                                base + a.wsa_conv[0], a.wsa_conv_bytes[0], device, sm, &reduce_m));
+                else
+                    FOSVOS_TRY(first_wgrad_impl(frame, gact(0), g->conv_w[0], g->conv_b[0], N, H, W, kCout[0], acc,
+                                                base + a.wsa_conv[0], a.wsa_conv_bytes[0], device, sa, &reduce));
                 break;
             }
             const bool from_pool = (c == first) && s > 0;  // its input is the pool output; conv 1 reads conv 0
@@ -272,14 +287,16 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
             const bool middle = (last - first == 2) && c == last - 1;
             if (!middle)
                 FOSVOS_TRY(wgrad_impl(xin, gact(c), g->conv_w[c], g->conv_b[c], N, hh, ww, kCin[c], kCout[c], acc,
-                                      base + a.wsa_conv[c], a.wsa_conv_bytes[c], device, sa, &reduce, tail && s <= tail_stages));
+                                      base + a.wsa_conv[c], a.wsa_conv_bytes[c], device, sa,
+                                      (offload && s == 1) ? &reduce_m : &reduce, tail && s <= tail_stages));
             FOSVOS_TRY(fosvos_conv3x3_dgrad(gact(c), w->conv_wd[c], mask, nullptr, dx, N, hh, ww, kCin[c], kCout[c], ws,
                                             a.ws_bytes, device, sm));
             const bool skip_event = (last - first == 2) && c == last;  // gact(last-1): covered by the middle conv's event
             if (!from_pool && !skip_event) FOSVOS_TRY(publish(c - 1));
             if (middle)
                 FOSVOS_TRY(wgrad_impl(xin, gact(c), g->conv_w[c], g->conv_b[c], N, hh, ww, kCin[c], kCout[c], acc,
-                                      base + a.wsa_conv[c], a.wsa_conv_bytes[c], device, sa, &reduce, tail && s <= tail_stages));
+                                      base + a.wsa_conv[c], a.wsa_conv_bytes[c], device, sa,
+                                      (offload && s == 1) ? &reduce_m : &reduce, tail && s <= tail_stages));
         }
         if (s > 0)  // pool backward into the previous stage's output gradient, its ReLU mask fused
             FOSVOS_TRY(fosvos_maxpool2x2_ceil_bwd(act(kLastOfStage[s - 1]), reinterpret_cast<const uint16_t *>(base + a.gpooled[s - 1]),
@@ -292,9 +309,14 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
             // bytes - are published here, so their all-reduce runs under the rest of the backward pass.
             FOSVOS_TRY(wgrad_reduce_all(&reduce, device, sa));
             if (buckets && s >= 3) FOSVOS_HIP_CHECK(hipEventRecord(ev[kBucketEvent0 + (4 - s)], sa));
+            if (offload && s == 1) FOSVOS_HIP_CHECK(hipEventRecord(ev[kStage2WgradEvent], sa));
         }
     }
     FOSVOS_TRY(wgrad_reduce_all(&reduce, device, sa));  // slabs -> dw / db for all (remaining) layers
+    if (offload) {  // stage 2's and conv1_1's reductions: on the main stream, beside conv1_2's weight-gradient kernel
+        FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[kStage2WgradEvent], 0));
+        FOSVOS_TRY(wgrad_reduce_all(&reduce_m, device, sm));
+    }
     if (buckets) {
         FOSVOS_HIP_CHECK(hipEventRecord(ev[kBucketEvent0 + 2], sa));  // buckets 2 and 3: everything
         std::lock_guard<std::mutex> lock(g_events_mutex);
