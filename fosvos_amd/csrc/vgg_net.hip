@@ -70,7 +70,9 @@ Arena make_arena(int N, int H, int W) {
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kCout[c], kCin[c]));   // dgrad split-K
     }
     for (int s = 1; s < 5; ++s) {
-        a.wsa_side_bytes[s - 1] = up256(fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16));
+        // (also the split-K workspace of the side layer's FORWARD conv when that runs on the auxiliary stream)
+        a.wsa_side_bytes[s - 1] = up256(std::max(fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16),
+                                                 fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16)));
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16));
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], 16, kStageCh[s]));
     }
@@ -130,15 +132,27 @@ extern "C" size_t fosvos_vgg_arena_bytes(int N, int H, int W) {
     return make_arena(N, H, W).total;
 }
 
-extern "C" int fosvos_vgg_forward(const fosvos_vgg_weights *w, const float *frame, int N, int H, int W, void *arena,
-                                  size_t arena_bytes, float *fused, float *const side_out[4], int device,
-                                  void *stream) {
+// aux_stream (optional): the four side_prep convs (16 output channels: memory-bound, 120 us per five 480x854 frames) run on
+// it, beside the backbone's MFMA-bound convs of the NEXT stage, instead of between them; `stream` waits for them in front of
+// the head.  The caller sees single-stream semantics on `stream`.
+extern "C" int fosvos_vgg_forward_streams(const fosvos_vgg_weights *w, const float *frame, int N, int H, int W, void *arena,
+                                          size_t arena_bytes, float *fused, float *const side_out[4], int device,
+                                          void *stream, void *aux_stream) {
     const Arena a = make_arena(N, H, W);
     FOSVOS_TRY(check_net(w, frame, arena, N, H, W, arena_bytes, a, "vgg_forward"));
     FOSVOS_REQUIRE(fused, FOSVOS_E_ARG, "vgg_forward: null output");
     char *base = reinterpret_cast<char *>(arena);
     auto act = [&](int c) { return reinterpret_cast<uint16_t *>(base + a.act[c]); };
     void *ws = base + a.ws;
+    hipStream_t sm = (hipStream_t)stream;
+    const bool par = aux_stream != nullptr && aux_stream != stream;
+    hipStream_t sa = par ? (hipStream_t)aux_stream : sm;
+    hipEvent_t *ev = nullptr;
+    if (par) {
+        EventPool *pool = nullptr;
+        FOSVOS_ENTER(device);
+        FOSVOS_TRY(get_events(device, &ev, &pool));
+    }
     const uint16_t *x = nullptr;
     for (int c = 0; c < kNConv; ++c) {
         const int s = kStageOf[c];
@@ -157,9 +171,21 @@ extern "C" int fosvos_vgg_forward(const fosvos_vgg_weights *w, const float *fram
             }
         }
         x = act(c);
-        if (s > 0 && c == kLastOfStage[s])
+        if (s > 0 && c == kLastOfStage[s]) {
+            if (par) {  // the stage output is complete on `stream`: the side conv may read it on the other one
+                FOSVOS_HIP_CHECK(hipEventRecord(ev[c], sm));
+                FOSVOS_HIP_CHECK(hipStreamWaitEvent(sa, ev[c], 0));
+            }
+            // (on the auxiliary stream the layer's own weight-gradient workspace doubles as its split-K workspace: `ws`
+            // is in use by the backbone convs running beside it)
             FOSVOS_TRY(fosvos_conv3x3_fwd(x, w->side_wf[s - 1], w->side_b[s - 1], base + a.side[s - 1], N, a.sh[s], a.sw[s],
-                                          kStageCh[s], 16, FOSVOS_CONV_OUT_F32, ws, a.ws_bytes, device, stream));
+                                          kStageCh[s], 16, FOSVOS_CONV_OUT_F32, par ? base + a.wsa_side[s - 1] : ws,
+                                          par ? a.wsa_side_bytes[s - 1] : a.ws_bytes, device, sa));
+        }
+    }
+    if (par) {  // join: the head reads the four side maps
+        FOSVOS_HIP_CHECK(hipEventRecord(ev[13], sa));
+        FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[13], 0));
     }
     const float *side[4];
     int hs[4], wsz[4];
@@ -170,6 +196,12 @@ extern "C" int fosvos_vgg_forward(const fosvos_vgg_weights *w, const float *fram
     }
     return fosvos_head_fwd(side, hs, wsz, w->filt, w->filt1, w->dsn_w, w->dsn_b, w->fuse_w, w->fuse_b, fused, side_out, N, H,
                            W, device, stream);
+}
+
+extern "C" int fosvos_vgg_forward(const fosvos_vgg_weights *w, const float *frame, int N, int H, int W, void *arena,
+                                  size_t arena_bytes, float *fused, float *const side_out[4], int device,
+                                  void *stream) {
+    return fosvos_vgg_forward_streams(w, frame, N, H, W, arena, arena_bytes, fused, side_out, device, stream, nullptr);
 }
 
 extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg_grads *g, const float *frame, int N,

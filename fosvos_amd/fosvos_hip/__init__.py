@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 CONV_RELU = 1
 CONV_OUT_F32 = 2
 
@@ -159,6 +159,8 @@ SIGNATURES = {
     "fosvos_profile_stop": (c_int, [c_int, POINTER(ProfileRecord), c_int, POINTER(c_int)]),
     "fosvos_vgg_forward": (c_int, [POINTER(VggWeights), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                    POINTER(c_void_p), c_int, c_void_p]),
+    "fosvos_vgg_forward_streams": (c_int, [POINTER(VggWeights), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
+                                   POINTER(c_void_p), c_int, c_void_p, c_void_p]),
     "fosvos_vgg_backward": (c_int, [POINTER(VggWeights), POINTER(VggGrads), c_void_p, c_int, c_int, c_int, c_void_p,
                                     c_size_t, c_void_p, POINTER(c_void_p), c_int, c_void_p, c_void_p]),
 }

@@ -383,8 +383,12 @@ def native_forward(P, packs, pool: ArenaPool, x: torch.Tensor, with_side_out: bo
     so = ptr_array4([o.data_ptr() for o in outs]) if with_side_out else None
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     t0 = ops._pb()
-    check(lib().fosvos_vgg_forward(ctypes.byref(w), x.data_ptr(), N, H, W, ap, an, fused.data_ptr(), so, idx,
-                                   torch.cuda.current_stream(idx).cuda_stream), "vgg_forward")
+    # batched passes: the side_prep convs ride on the auxiliary stream beside the next stage's backbone convs (+0.4 % on the
+    # five-frame training pass; FOSVOS_FWD_AUX=0: one stream).  A single frame stays on one stream: its kernels are too
+    # short for the four event pairs to pay (inference protocol: 0.586 vs 0.564 ms per frame).
+    aux = pool.aux_stream(idx) if N >= 2 and os.environ.get("FOSVOS_FWD_AUX", "1") != "0" else 0
+    check(lib().fosvos_vgg_forward_streams(ctypes.byref(w), x.data_ptr(), N, H, W, ap, an, fused.data_ptr(), so, idx,
+                                           torch.cuda.current_stream(idx).cuda_stream, aux or None), "vgg_forward")
     ops._pe(t0, "vgg_forward", 2.0 * 129.114e9 * N * H * W / (480 * 854), 0.0)
     if not keep:
         pool.give(N, H, W, arena)

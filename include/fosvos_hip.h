@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 10
+#define FOSVOS_ABI_VERSION 11
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -411,6 +411,13 @@ size_t fosvos_vgg_arena_bytes(int N, int H, int W);
 /* fused: [N,1,H,W] fp32; side_out: four [N,1,H,W] fp32 buffers or NULL.  The arena keeps what backward needs. */
 int fosvos_vgg_forward(const fosvos_vgg_weights *w, const float *frame, int N, int H, int W, void *arena,
                        size_t arena_bytes, float *fused, float *const side_out[4], int device, void *stream);
+/* The same pass with a second stream of the same device (or NULL = fosvos_vgg_forward): the four side_prep convs
+ * (16 output channels, memory-bound) are issued on aux_stream beside the next stage's backbone convs; `stream` waits for
+ * them (events of the pool described under fosvos_vgg_backward) in front of the head, so the caller sees single-stream
+ * semantics on `stream`.  Results are bit-identical to fosvos_vgg_forward. */
+int fosvos_vgg_forward_streams(const fosvos_vgg_weights *w, const float *frame, int N, int H, int W, void *arena,
+                               size_t arena_bytes, float *fused, float *const side_out[4], int device, void *stream,
+                               void *aux_stream);
 /* d_fused / d_side_out: upstream gradients ([N,1,H,W] fp32; d_fused or all four d_side_out may be NULL).
  * Must follow a fosvos_vgg_forward on the same arena, frame and shape.
  * aux_stream (a second hipStream_t of the same device, or NULL): when given, every weight-gradient kernel is
