@@ -7,6 +7,7 @@ set -o pipefail
 TAG=${1:-rXX}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
+rm -rf $OUT  # (a previous call's per-pid CSVs would be picked up by the summarising scripts)
 mkdir -p $OUT
 cd $ROOT
 echo "== tests"; timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; rc=$?; tail -3 $OUT/pytest_gpu.log
