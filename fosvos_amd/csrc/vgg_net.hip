@@ -85,10 +85,12 @@ Arena make_arena(int N, int H, int W) {
 }
 
 // ---- the library's only persistent state: timing-disabled events for the two-stream backward
-// 13 conv-output gradients + head + fork + join + d_side[0..2] (aux -> main) + 3 gradient-bucket events (19..21)
-// + "stage 2's weight gradients are queued" (22)
-constexpr int kNEvents = 23;
-constexpr int kStage2WgradEvent = 22;  // stage 2's weight-gradient kernels are queued on the wgrad stream
+// 13 conv-output gradients + head + fork + join + d_side[0..2] (aux -> main) + gradient-bucket events: stage 5, 4, 3 (19..21)
+// and "everything" (22) + "stage 2's weight gradients are queued" (23) + "the main stream's share of the tail is done" (24)
+constexpr int kNEvents = 25;
+constexpr int kBucketFinalEvent = 22;  // every gradient the wgrad stream produces is final
+constexpr int kStage2WgradEvent = 23;  // stage 2's weight-gradient kernels are queued on the wgrad stream
+constexpr int kMainTailEvent = 24;     // the reductions offloaded to the main stream's end are done
 constexpr int kBucketEvent0 = 19;
 struct EventPool {
     hipEvent_t ev[kNEvents];
@@ -337,10 +339,10 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
         if (s >= 1) {
             // The slab reductions queued so far run now (two launches) instead of all at the end: the weight-gradient
             // stream has slack, and what stands between the last data-gradient kernel and the optimizer step shrinks to
-            // stage 1's own reduction.  Data-parallel step: stage 5 (bucket 0) and stage 4 (bucket 1) - 87 % of the gradient
+            // stage 1's own reduction.  Data-parallel step: stages 5, 4, 3 (buckets 0-2) - 97 % of the gradient
             // bytes - are published here, so their all-reduce runs under the rest of the backward pass.
             FOSVOS_TRY(wgrad_reduce_all(&reduce, device, sa));
-            if (buckets && s >= 3) FOSVOS_HIP_CHECK(hipEventRecord(ev[kBucketEvent0 + (4 - s)], sa));
+            if (buckets && s >= 2) FOSVOS_HIP_CHECK(hipEventRecord(ev[kBucketEvent0 + (4 - s)], sa));
             if (offload && s == 1) FOSVOS_HIP_CHECK(hipEventRecord(ev[kStage2WgradEvent], sa));
         }
     }
@@ -349,8 +351,9 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
         FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[kStage2WgradEvent], 0));
         FOSVOS_TRY(wgrad_reduce_all(&reduce_m, device, sm));
     }
+    if (buckets) FOSVOS_HIP_CHECK(hipEventRecord(ev[kMainTailEvent], sm));  // (also covers the head's main-stream share)
     if (buckets) {
-        FOSVOS_HIP_CHECK(hipEventRecord(ev[kBucketEvent0 + 2], sa));  // buckets 2 and 3: everything
+        FOSVOS_HIP_CHECK(hipEventRecord(ev[kBucketFinalEvent], sa));  // buckets 3 and 4: everything the wgrad stream owes
         std::lock_guard<std::mutex> lock(g_events_mutex);
         pool->buckets_recorded = true;
     }
@@ -362,7 +365,7 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
 }
 
 extern "C" int fosvos_vgg_grad_bucket_wait(int device, int bucket, void *stream) {
-    FOSVOS_REQUIRE(bucket >= 0 && bucket < 4, FOSVOS_E_ARG, "vgg_grad_bucket_wait: bucket %d not in 0..3", bucket);
+    FOSVOS_REQUIRE(bucket >= 0 && bucket < 5, FOSVOS_E_ARG, "vgg_grad_bucket_wait: bucket %d not in 0..4", bucket);
     FOSVOS_ENTER(device);
     hipEvent_t *ev = nullptr;
     EventPool *pool = nullptr;
@@ -372,6 +375,11 @@ extern "C" int fosvos_vgg_grad_bucket_wait(int device, int bucket, void *stream)
         FOSVOS_REQUIRE(pool->buckets_recorded, FOSVOS_E_ARG,
                        "vgg_grad_bucket_wait: the last fosvos_vgg_backward on device %d did not set grads.bucket_events", device);
     }
-    FOSVOS_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ev[kBucketEvent0 + (bucket < 2 ? bucket : 2)], 0));
+    if (bucket < 3) {
+        FOSVOS_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ev[kBucketEvent0 + bucket], 0));
+    } else {  // the tail buckets: the wgrad stream's last reduction AND what the pass left at the end of its main stream
+        FOSVOS_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ev[kBucketFinalEvent], 0));
+        FOSVOS_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ev[kMainTailEvent], 0));
+    }
     return FOSVOS_OK;
 }

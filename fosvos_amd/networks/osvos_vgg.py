@@ -105,7 +105,7 @@ class OSVOS_VGG(nn.Module):
 
     @publish_grad_buckets.setter
     def publish_grad_buckets(self, value):
-        """True: backward passes publish their gradients in completion order (stage 5, stage 4, the rest) through
+        """True: backward passes publish their gradients in completion order (stage 5, stage 4, stage 3, the rest) through
         ``wait_grad_bucket`` - what the data-parallel loops overlap their bucketed all-reduce with."""
         self._packs.publish_grad_buckets = bool(value)
 

@@ -70,8 +70,9 @@ def split_accumulation(avg_grad_every_n: int, world: int) -> int:
 
 # Gradient buckets in the order the backward pass completes them, by parameter-name prefix (state_dict names of
 # OSVOS_VGG).  Bucket index = the `bucket` argument of fosvos_vgg_grad_bucket_wait.
-VGG_BUCKETS = (("stages.4.",), ("stages.3.",), ("stages.0.", "stages.1.", "stages.2."),
+VGG_BUCKETS = (("stages.4.",), ("stages.3.",), ("stages.2.",), ("stages.0.", "stages.1."),
                ("side_prep.", "score_dsn.", "fuse."))
+VGG_EARLY_BUCKETS = 3  # buckets 0-2 are published while the backward pass is still running (97 % of the bytes)
 
 
 def batch_label_counts(gts: torch.Tensor) -> Optional[torch.Tensor]:
@@ -183,7 +184,7 @@ class GradSync:
         sync.finish()               in front of optimizer.step(): the current stream waits for all of it
 
     On the GPU each bucket's collective waits only for that bucket's gradients (``net.wait_grad_bucket``), so the
-    stage-5 and stage-4 transfers (87 % of the bytes) run under the rest of the backward pass.  With CPU tensors (gloo
+    stage-5, -4 and -3 transfers (97 % of the bytes) run under the rest of the backward pass.  With CPU tensors (gloo
     tests) the same calls run the same bucketed arithmetic without streams."""
 
     def __init__(self, net, flat: "FlatGrads"):
@@ -209,7 +210,7 @@ class GradSync:
 
             def wait(b: int) -> None:
                 net.wait_grad_bucket(b, comm)
-                if b >= 2:  # the tail buckets also hold gradients the host side adds on the main stream (score_dsn)
+                if b >= VGG_EARLY_BUCKETS:  # the tail buckets also hold gradients the host side adds on the main stream (score_dsn)
                     comm.wait_stream(main)
 
             with torch.cuda.stream(comm):

@@ -121,8 +121,9 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     sync = parallel.GradSync(net, flat)
 
     # single process on the GPU: the optimizer step is split by gradient bucket (see run_group); FOSVOS_SPLIT_STEP=0 = one step
-    early_buckets = [b for b, pre in enumerate(parallel.VGG_BUCKETS[:2]) if b < len(flat.slices)]
-    split_step = (world == 1 and flat.flat.is_cuda and hasattr(net, 'wait_grad_bucket') and len(flat.slices) > 2
+    early_buckets = [b for b in range(parallel.VGG_EARLY_BUCKETS) if b < len(flat.slices)]
+    split_step = (world == 1 and flat.flat.is_cuda and hasattr(net, 'wait_grad_bucket')
+                  and len(flat.slices) > parallel.VGG_EARLY_BUCKETS
                   and hasattr(optimizer, '_tables') and os.environ.get('FOSVOS_SPLIT_STEP', '1') != '0')
     late_buckets = [b for b in range(len(flat.slices)) if b not in early_buckets]
     early_params = [p for b in early_buckets for p in flat.bucket_params[b]]
@@ -239,7 +240,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
 
         if counter_gradient % local_accum == 0:
             if split_step:
-                # Stages 5 and 4 hold 87 % of the parameters and their gradients are final early in the backward pass.
+                # Stages 5-3 hold 97 % of the parameters and their gradients are final well before the backward pass ends.
                 # Their share of the optimizer step, the zeroing of their gradients and the repacking of their weights are
                 # queued on the main stream right here - behind the data-gradient chain, while the weight-gradient stream
                 # is still working through stages 3-1 - and only the small rest waits for that stream.

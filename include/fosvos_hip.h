@@ -397,8 +397,8 @@ typedef struct fosvos_vgg_grads {
                                    * end of the call; the caller joins (stream waits on aux_stream) before it reads
                                    * them, and must not reuse this arena before that.  Lets the next forward pass
                                    * (other arena, same weights) overlap the tail of the weight-gradient kernels. */
-    int bucket_events;            /* != 0: publish the gradients in three pieces as the pass finishes them (stage 5,
-                                   * stage 4, the rest) so that a data-parallel caller can start each piece's
+    int bucket_events;            /* != 0: publish the gradients in four pieces as the pass finishes them (stage 5,
+                                   * stage 4, stage 3, the rest) so that a data-parallel caller can start each piece's
                                    * all-reduce early: see fosvos_vgg_grad_bucket_wait. */
     int last_pass_of_cycle;       /* != 0: a hint - no forward pass follows this backward pass before the optimizer step
                                    * (the last one of an accumulation cycle), so the weight-gradient kernels of the first
@@ -430,8 +430,9 @@ int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg_grads *g, 
                         int device, void *stream, void *aux_stream);
 /* Make `stream` wait until gradient bucket `bucket` of the LAST fosvos_vgg_backward on this device (called with
  * grads.bucket_events != 0) is complete in its buffers: 0 = conv5_1..conv5_3 (stages.4), 1 = conv4_1..conv4_3
- * (stages.3), 2 = conv1_1..conv3_3, 3 = side_prep / score_dsn / fuse (2 and 3 complete together, at the end of the
- * pass).  Nothing blocks on the host.  The reference has no collective; this is the hook the
+ * (stages.3), 2 = conv3_1..conv3_3 (stages.2) - 97 % of the gradient bytes, each published as the pass finishes it - then
+ * 3 = conv1_1..conv2_2, 4 = side_prep / score_dsn / fuse (3 and 4 complete together, at the end of the pass, on both of
+ * its streams).  Nothing blocks on the host.  The reference has no collective; this is the hook the
  * RCCL gradient all-reduce of BASELINE.json's north_star overlaps the backward pass with. */
 int fosvos_vgg_grad_bucket_wait(int device, int bucket, void *stream);
 

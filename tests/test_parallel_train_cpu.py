@@ -175,10 +175,11 @@ def test_flat_grad_buckets_of_the_real_module():
     net = OSVOS_VGG(pretrained=0)
     named = list(net.named_parameters())
     flat = parallel.FlatGrads([p for _, p in named], names=[n for n, _ in named])
-    assert len(flat.slices) == 4
+    assert len(flat.slices) == 5
     sizes = [hi - lo for lo, hi in flat.slices]
     assert sizes[0] == 3 * (512 * 512 * 9 + 512)                           # stages.4
     assert sizes[1] == 512 * 256 * 9 + 512 + 2 * (512 * 512 * 9 + 512)     # stages.3
+    assert sizes[2] == 256 * 128 * 9 + 256 + 2 * (256 * 256 * 9 + 256)     # stages.2
     covered = sum(sizes)
     frozen = sum(p.numel() for n, p in named if n.startswith("upscale"))
     assert frozen == 349520
