@@ -174,15 +174,18 @@ extern "C" int fosvos_vgg_forward_streams(const fosvos_vgg_weights *w, const flo
         }
         x = act(c);
         if (s > 0 && c == kLastOfStage[s]) {
-            if (par) {  // the stage output is complete on `stream`: the side conv may read it on the other one
+            // the last stage's side conv has nothing left to run beside: it stays on `stream` (the round trip through the
+            // other stream cost 25 us in front of the head)
+            const bool on_aux = par && s < 4;
+            if (on_aux) {  // the stage output is complete on `stream`: the side conv may read it on the other one
                 FOSVOS_HIP_CHECK(hipEventRecord(ev[c], sm));
                 FOSVOS_HIP_CHECK(hipStreamWaitEvent(sa, ev[c], 0));
             }
             // (on the auxiliary stream the layer's own weight-gradient workspace doubles as its split-K workspace: `ws`
             // is in use by the backbone convs running beside it)
             FOSVOS_TRY(fosvos_conv3x3_fwd(x, w->side_wf[s - 1], w->side_b[s - 1], base + a.side[s - 1], N, a.sh[s], a.sw[s],
-                                          kStageCh[s], 16, FOSVOS_CONV_OUT_F32, par ? base + a.wsa_side[s - 1] : ws,
-                                          par ? a.wsa_side_bytes[s - 1] : a.ws_bytes, device, sa));
+                                          kStageCh[s], 16, FOSVOS_CONV_OUT_F32, on_aux ? base + a.wsa_side[s - 1] : ws,
+                                          on_aux ? a.wsa_side_bytes[s - 1] : a.ws_bytes, device, on_aux ? sa : sm));
         }
     }
     if (par) {  // join: the head reads the four side maps

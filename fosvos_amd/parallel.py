@@ -145,8 +145,14 @@ class FlatGrads:
         if buckets is None:
             self.flat.zero_()
             return
-        for b in buckets:
-            lo, hi = self.slices[b]
+        spans = sorted(self.slices[b] for b in buckets)
+        merged: List[List[int]] = []
+        for lo, hi in spans:  # adjacent slices share one memset (stages 5-3 are one run of the buffer)
+            if merged and merged[-1][1] == lo:
+                merged[-1][1] = hi
+            else:
+                merged.append([lo, hi])
+        for lo, hi in merged:
             self.flat[lo:hi].zero_()
 
     def all_reduce(self, async_op: bool = False):
