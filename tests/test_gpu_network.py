@@ -321,6 +321,36 @@ def test_grouped_micro_batches_equal_one_by_one(monkeypatch):
         print(f"[group {group}] worst delta rel-L2 vs one-by-one {max(ratios):.3e}")
 
 
+def test_scheduling_switches_do_not_change_the_weights(monkeypatch):
+    """What `train_online._train` does for speed only - the optimizer step split by gradient bucket (stages 5-3 stepped,
+    zeroed and repacked behind the data-gradient chain, the rest behind the weight-gradient stream: FOSVOS_SPLIT_STEP) and
+    the side_prep convs of a batched forward pass on the auxiliary stream (FOSVOS_FWD_AUX) - reorders launches, never
+    arithmetic: the weights after two optimizer steps are bit-identical with each switch off."""
+    import train_online
+    from util.network_provider import VGGOnlineProvider
+    frames = [O.synthetic_frame(1, 40, 70, seed=90 + i) for i in range(5)]
+    loader = [{"image": x, "gt": gt} for x, gt in frames]
+    runs = {}
+    for tag, env in (("default", {}), ("one_step", {"FOSVOS_SPLIT_STEP": "0"}), ("one_stream_fwd", {"FOSVOS_FWD_AUX": "0"})):
+        for k_, v_ in (("FOSVOS_SPLIT_STEP", "1"), ("FOSVOS_FWD_AUX", "1")):
+            monkeypatch.setenv(k_, env.get(k_, v_))
+        net, _ = make_net(23)
+        prov = VGGOnlineProvider.__new__(VGGOnlineProvider)
+        prov.network = net
+        prov.name = "vgg16"
+        opt = prov.get_optimizer(learning_rate=1e-8)
+        train_online.data_parallel = False
+        ret = train_online._train(prov, loader, opt, _NullWriter(), "switches", 0, 2, 5, 10 ** 9)  # 10 iterations, 2 steps
+        assert ret["iterations"] == 10
+        runs[tag] = ({n_: p.detach().clone() for n_, p in net.named_parameters()}, ret["loss"])
+    base_w, base_loss = runs["default"]
+    for tag in ("one_step", "one_stream_fwd"):
+        w, loss = runs[tag]
+        assert loss == base_loss, tag
+        for n_ in base_w:
+            assert torch.equal(w[n_], base_w[n_]), (tag, n_)
+
+
 def test_shipped_offline_train_vs_golden(golden):
     """`train_offline._train` ITSELF on the golden's schedule (4 iterations of epoch 60 of 240, step every 2, five
     deeply supervised losses, src/train_offline.py:77-110): the five loss values of the epoch and the applied weight
