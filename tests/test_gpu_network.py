@@ -467,28 +467,37 @@ def test_gradient_buckets_are_published_in_completion_order():
     plain = {n_: p.grad.clone() for n_, p in net.named_parameters() if p.grad is not None}
     with pytest.raises(FosvosHipError):
         net.wait_grad_bucket(0)
-    net2, _ = make_net(16)
-    named = list(net2.named_parameters())
-    flat = parallel.FlatGrads([p for _, p in named], names=[n_ for n_, _ in named])
-    net2.accumulate_grads_in_place = True
-    net2.defer_wgrad_join = True
-    net2.publish_grad_buckets = True
-    cbce(net2(x.to(DEV))[-1], gt.to(DEV), size_average=False).backward()
-    side = torch.cuda.Stream()
-    snaps = []
-    with torch.cuda.stream(side):
-        for b, (lo, hi) in enumerate(flat.slices):
-            net2.wait_grad_bucket(b, side)
-            snaps.append(flat.flat[lo:hi].clone())  # ordered behind bucket b's event only
-    side.synchronize()
-    net2.join_gradients()
-    torch.cuda.synchronize()
-    for (lo, hi), snap in zip(flat.slices, snaps):
-        assert torch.equal(snap, flat.flat[lo:hi])
-    for n_, p in net2.named_parameters():
-        if n_ in plain:
-            assert torch.equal(p.grad, plain[n_]), n_
-    net2.defer_wgrad_join = False
+    # ... also in the last pass of a cycle, where part of the reductions runs at the end of the MAIN stream (the tail buckets
+    # then wait for both streams of the pass) and the trailing weight-gradient kernels take other pixel splits (fp32 order)
+    for last_pass in (False, True):
+        net2, _ = make_net(16)
+        named = list(net2.named_parameters())
+        flat = parallel.FlatGrads([p for _, p in named], names=[n_ for n_, _ in named])
+        assert len(flat.slices) == 5
+        net2.accumulate_grads_in_place = True
+        net2.defer_wgrad_join = True
+        net2.publish_grad_buckets = True
+        net2.last_pass_of_cycle = last_pass
+        cbce(net2(x.to(DEV))[-1], gt.to(DEV), size_average=False).backward()
+        side = torch.cuda.Stream()
+        snaps = []
+        with torch.cuda.stream(side):
+            for b, (lo, hi) in enumerate(flat.slices):
+                net2.wait_grad_bucket(b, side)
+                snaps.append(flat.flat[lo:hi].clone())  # ordered behind bucket b's event(s) only
+        side.synchronize()
+        net2.join_gradients()
+        torch.cuda.synchronize()
+        for (lo, hi), snap in zip(flat.slices, snaps):
+            assert torch.equal(snap, flat.flat[lo:hi])
+        for n_, p in net2.named_parameters():
+            if n_ in plain:
+                if last_pass and n_.startswith("stages.0."):  # 256 pixel splits instead of 192: another summation order
+                    torch.testing.assert_close(p.grad, plain[n_], rtol=1e-3, atol=1e-3 * plain[n_].abs().max().item())
+                else:
+                    assert torch.equal(p.grad, plain[n_]), n_
+        net2.defer_wgrad_join = False
+        net2.last_pass_of_cycle = False
 
 
 def test_inplace_grad_accumulation_matches_autograd():
