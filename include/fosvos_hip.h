@@ -424,7 +424,7 @@ int fosvos_vgg_forward_streams(const fosvos_vgg_weights *w, const float *frame, 
  * issued on it while the data-gradient chain stays on `stream`; the two are ordered by events (a layer's wgrad
  * waits for that layer's output gradient; `stream` waits for the last wgrad before the call's work is complete
  * in stream order), so the caller sees ordinary single-stream semantics on `stream`.  The events are the one
- * piece of persistent state the library keeps (16 timing-disabled hipEvents per device, created on first use). */
+ * piece of persistent state the library keeps (25 timing-disabled hipEvents per device, created on first use). */
 int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg_grads *g, const float *frame, int N, int H, int W,
                         void *arena, size_t arena_bytes, const float *d_fused, const float *const d_side_out[4],
                         int device, void *stream, void *aux_stream);
