@@ -46,6 +46,9 @@ sys.path.insert(0, os.path.join(ROOT, "fosvos_amd"))
 
 H, W = 480, 854
 AVG_GRAD_EVERY_N = 5
+# untimed steps of the same loop in front of the W warm-up steps: ~60 ms of load, so that the timed window does not start on a
+# device that is still raising its clocks after the idle start-up of the process (FOSVOS_BENCH_PRECONDITION=0 turns it off)
+PRECONDITION_STEPS = int(os.environ.get("FOSVOS_BENCH_PRECONDITION", "70"))
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 CONV_KERNEL_PREFIXES = ("k_conv3x3_igemm", "k_wgrad3x3", "k_wgrad_first")  # the MFMA kernels the roofline object is about
 
@@ -198,6 +201,12 @@ def main():
         def run(n_steps):
             return train_online._train(prov, batch, opt, _NullWriter(), "bench", 0, n_steps, accum, 10 ** 9)
 
+        # Device wake-up, in front of the W warm-up steps (untimed, declared in the JSON line): after an idle gap - process
+        # start-up, model construction - the device's clocks take a few milliseconds of load to come up, which a short timed
+        # window would otherwise measure (tools/train_call_probe.py: 20 steps take 19.2 ms after 300 ms of idle, 17.4 ms
+        # right behind another call).  The same workload, PRECONDITION_STEPS steps of it.
+        if PRECONDITION_STEPS > 0:
+            run(PRECONDITION_STEPS)
         run(args.warmup)
         barrier()
         t0 = time.perf_counter()
@@ -242,6 +251,7 @@ def main():
         "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic",
+        "precondition_steps": PRECONDITION_STEPS,
         "backend": {"nccl": "nccl (RCCL)"}.get(backend, backend),
         "ranks": world,
         "distinct_devices": distinct,

@@ -108,6 +108,7 @@ class FlatGrads:
             cur += (p.numel() + 3) // 4 * 4
         self.flat = torch.zeros(cur, dtype=torch.float32, device=dev)
         self.numel = total
+        self._offsets = list(offs)
         for p, o in zip(self.params, offs):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
         # bucket b = one contiguous slice [lo, hi) of the flat buffer; without names: one bucket, everything.
@@ -139,6 +140,30 @@ class FlatGrads:
                     self.bucket_params.append([self.params[i] for i in run])
                     run = []
         self._works: list = []
+
+    @classmethod
+    def attach(cls, net, params: Iterable[torch.nn.Parameter], names: Optional[Sequence[str]] = None) -> "FlatGrads":
+        """The flat buffer of `net`: the one a previous loop attached, zeroed, while its parameters still point into it -
+        otherwise a new one.  (A new buffer per call of a training loop costs a 60 MB device allocation every second call:
+        the parameters keep the previous buffer alive until their `.grad` is re-pointed.)"""
+        params = list(params)
+        old = getattr(net, "_fosvos_flat_grads", None)
+        if old is not None and old.still_attached([p for p in params if p.requires_grad]):
+            old.zero()
+            return old
+        new = cls(params, names=names)
+        try:
+            net._fosvos_flat_grads = new
+        except Exception:  # a module that refuses attributes: just do without the cache
+            pass
+        return new
+
+    def still_attached(self, params: Sequence[torch.nn.Parameter]) -> bool:
+        if len(params) != len(self.params) or any(a is not b for a, b in zip(params, self.params)):
+            return False
+        base, esz = self.flat.data_ptr(), self.flat.element_size()
+        return all(p.grad is not None and p.grad.data_ptr() == base + o * esz and p.grad.numel() == p.numel()
+                   for p, o in zip(self.params, self._offsets))
 
     def zero(self, buckets: Optional[Sequence[int]] = None) -> None:
         """Zero the whole buffer, or only the slices of the given buckets."""

@@ -86,7 +86,7 @@ def _train(net_provider: NetworkProvider, data_loader_train, data_loader_test, o
     # gradients live in one flat fp32 buffer: the wgrad kernels accumulate straight into it, zeroing is one memset,
     # and under data parallelism it is the single all-reduce payload
     named = list(net.named_parameters())
-    flat = parallel.FlatGrads([p for _, p in named], names=[n for n, _ in named])
+    flat = parallel.FlatGrads.attach(net, [p for _, p in named], names=[n for n, _ in named])
     sync = parallel.GradSync(net, flat)
     device = next(net.parameters()).device
 
