@@ -51,7 +51,7 @@ summary["conv_mfma_family"] = {
 summary["conv_mfma_family"]["hbm_bytes_per_launch"] = (summary["conv_mfma_family"]["hbm_bytes_per_step"] /
                                                        summary["conv_mfma_family"]["launches_per_step"])
 summary["all_kernels_hbm_bytes_per_step"] = sum(r["hbm_bytes_per_step"] for r in rows.values())
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes, tools/round_profiles.sh) -- python3 bench.py "
+json.dump({"source": "FOSVOS_BENCH_PRECONDITION=0 rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes, tools/round_profiles.sh) -- python3 bench.py "
                      f"--steps {steps - 5} --warmup 5 --no-cpu-baseline --no-roofline --no-infer",
            "corrections": "bytes = KiB * 1024; FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B)",
            "steps_profiled": steps, "summary": summary, "per_kernel": rows}, open(out, "w"), indent=1)

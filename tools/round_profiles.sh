@@ -15,6 +15,8 @@ echo "== tests"; timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/py
 echo "== bench"; timeout -k 10 600 python bench.py > $OUT/bench_1gpu.json 2> $OUT/bench_1gpu.err || exit 1
 python tools/show_bench.py $OUT/bench_1gpu.json
 cd /tmp && export TMPDIR=/tmp
+# the profiled runs skip bench.py's device wake-up steps: the step counts in the summaries stay 80 (10 + 50 + 20) and 25 (5 + 20)
+export FOSVOS_BENCH_PRECONDITION=0
 echo "== kernel stats"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-infer > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
 echo "== pmc traffic"
