@@ -317,6 +317,11 @@ def main():
             "algorithmic_gflop_per_step": conv_flop / 1e9,
             "avg_launch_us": conv_ms / conv_calls * 1000.0,
             "device_ms_per_step_all_kernels": sum(a["ms"] for a in prof.records.values()) / n_prof,
+            # the same FLOPs over the WALL time of a step of the timed region (everything included: the two streams overlap,
+            # so the kernel durations above add up to more than the step; the non-MFMA kernels, launch gaps and the optimizer
+            # step are in it too): what the whole step sustains, next to what its kernels sustain while they run
+            "step_wall_tflops": conv_flop / 1e12 / (elapsed / args.steps),
+            "step_wall_frac": conv_flop / 1e12 / (elapsed / args.steps) / MFMA_BF16_PEAK_TFLOPS,
             "by_kernel": by_kernel,
         }
     if rank == 0 and not args.no_infer:
