@@ -198,10 +198,18 @@ class FlatGrads:
                 wait_bucket(b)
             self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
+    def all_reduce_wait(self, bucket: int) -> None:
+        """Make the current stream (the host, for CPU tensors) wait for bucket `bucket`'s collective of all_reduce_begin
+        only - what lets a loop step the parameters of an early bucket while the later ones are still on the wire."""
+        if bucket < len(self._works) and self._works[bucket] is not None:
+            self._works[bucket].wait()
+            self._works[bucket] = None
+
     def all_reduce_finish(self) -> None:
         """Make the current stream (the host, for CPU tensors) wait for every collective of all_reduce_begin."""
         for w in self._works:
-            w.wait()
+            if w is not None:
+                w.wait()
         self._works = []
 
 
@@ -248,6 +256,11 @@ class GradSync:
                 self.flat.all_reduce_begin(wait)
         else:
             self.flat.all_reduce_begin(None)
+
+    def wait_bucket(self, bucket: int) -> None:
+        """The current stream waits for bucket `bucket`'s all-reduce (begun by begin()) only."""
+        if self.active:
+            self.flat.all_reduce_wait(bucket)
 
     def finish(self) -> None:
         if self.active:

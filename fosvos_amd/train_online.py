@@ -120,9 +120,9 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     flat = parallel.FlatGrads.attach(net, [p for _, p in named], names=[n for n, _ in named])
     sync = parallel.GradSync(net, flat)
 
-    # single process on the GPU: the optimizer step is split by gradient bucket (see run_group); FOSVOS_SPLIT_STEP=0 = one step
+    # on the GPU the optimizer step is split by gradient bucket (see run_group); FOSVOS_SPLIT_STEP=0 = one step
     early_buckets = [b for b in range(parallel.VGG_EARLY_BUCKETS) if b < len(flat.slices)]
-    split_step = (world == 1 and flat.flat.is_cuda and hasattr(net, 'wait_grad_bucket')
+    split_step = (flat.flat.is_cuda and hasattr(net, 'wait_grad_bucket')
                   and len(flat.slices) > parallel.VGG_EARLY_BUCKETS
                   and hasattr(optimizer, '_tables') and os.environ.get('FOSVOS_SPLIT_STEP', '1') != '0')
     late_buckets = [b for b in range(len(flat.slices)) if b not in early_buckets]
@@ -244,13 +244,19 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
                 # Their share of the optimizer step, the zeroing of their gradients and the repacking of their weights are
                 # queued on the main stream right here - behind the data-gradient chain, while the weight-gradient stream
                 # is still working through stages 3-1 - and only the small rest waits for that stream.
+                # Data parallel: "final" means all-reduced - the early buckets' collectives were begun while the backward pass
+                # was still running, and each is waited for on its own.
                 net.publish_grad_buckets = False
                 for b in early_buckets:
-                    net.wait_grad_bucket(b)
+                    if world > 1:
+                        sync.wait_bucket(b)
+                    else:
+                        net.wait_grad_bucket(b)
                 optimizer.step(only=early_params, tag='early')
                 flat.zero(early_buckets)
                 net.prepack_weights(early_prefixes)
                 net.join_gradients()
+                sync.finish()
                 optimizer.step(only=late_params, tag='late')
                 flat.zero(late_buckets)
             else:

@@ -1,0 +1,101 @@
+"""Data-parallel online loop on the GPU with the REAL network: two gloo ranks share cuda:0 (what a one-GPU box allows;
+RCCL needs one device per rank) and run ``train_online._train`` with the accumulation micro-batches split between them -
+bucketed all-reduce begun behind the backward pass, the early buckets waited for one by one, the optimizer step split into
+its early and late halves, the tail buckets reduced on both streams of the pass.  The weights both ranks end with must
+equal each other bit for bit and equal the single-process run of the same function on all micro-batches to the gradient
+tolerance (the frames of a cycle are summed in another order: per rank, then across ranks).
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "fosvos_amd"))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GRAD_REL_L2 = 0.15   # tests/test_gpu_network.py: bf16 forward noise bounds what two summation orders may differ by
+N_FRAMES, AVG, LR, H, W = 8, 4, 1e-8, 40, 70
+
+
+class _Writer:
+    def add_scalar(self, *a, **k):
+        pass
+
+
+def _frames():
+    from oracle import osvos_ref as O
+    return [dict(zip(("image", "gt"), O.synthetic_frame(1, H, W, seed=170 + i))) for i in range(N_FRAMES)]
+
+
+def _train(loader, dp):
+    import train_online
+    from networks.osvos_vgg import OSVOS_VGG
+    from oracle import osvos_ref as O
+    from util.network_provider import VGGOnlineProvider
+    net = OSVOS_VGG(pretrained=0)
+    sd = O.make_state_dict(29, "kaiming")
+    net.load_state_dict(sd)
+    prov = VGGOnlineProvider.__new__(VGGOnlineProvider)
+    prov.network = net.to(DEV)
+    prov.name = "vgg16"
+    opt = prov.get_optimizer(learning_rate=LR)
+    train_online.data_parallel = dp
+    ret = train_online._train(prov, loader, opt, _Writer(), "dp", 0, 1, AVG, 10 ** 9)  # one epoch: 2 optimizer steps
+    torch.cuda.synchronize()
+    return {k: v.detach().cpu() for k, v in prov.network.state_dict().items()}, sd, ret
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import parallel
+    assert parallel.init_distributed("gloo")
+    w, _, ret = _train(_frames()[rank::world], True)
+    torch.save({"w": w, "iterations": ret["iterations"]}, os.path.join(out_dir, f"dp{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_online_dp_on_gpu_equals_single_process(tmp_path):
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r), "2", str(port), str(tmp_path)])
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    res = [torch.load(os.path.join(str(tmp_path), f"dp{r}.pt")) for r in range(2)]
+    assert res[0]["iterations"] == res[1]["iterations"] == N_FRAMES // 2
+    ref, sd, ret = _train(_frames(), False)
+    assert ret["iterations"] == N_FRAMES
+    moved = 0
+    for k in ref:
+        assert torch.equal(res[0]["w"][k], res[1]["w"][k]), k  # the replicas stay bit-identical
+        d_ref = (ref[k] - sd[k]).double().reshape(-1)
+        d_got = (res[0]["w"][k] - sd[k]).double().reshape(-1)
+        if k.startswith(("upscale", "score_dsn")):
+            assert float(d_got.abs().max()) == 0.0, k
+            continue
+        if float(d_ref.abs().max()) == 0.0:
+            continue
+        ulp = float(np.spacing(np.float32(max(sd[k].abs().max().item(), 1e-30))))
+        noise = 2 * ulp * float(np.sqrt(d_ref.numel()))
+        ratio = max(float((d_got - d_ref).norm()) - noise, 0.0) / float(d_ref.norm())
+        assert ratio <= GRAD_REL_L2, (k, ratio)
+        moved += 1
+    assert moved >= 30
+
+
+if __name__ == "__main__":
+    _worker(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
