@@ -100,6 +100,25 @@ int head_bwd_check(const HeadBwdArgs &a);
 int head_bwd_scale(const HeadBwdArgs &a, int s, void *stream);
 int head_bwd_finish(const HeadBwdArgs &a, void *stream);
 
+}  // namespace fosvos
+// The caller-owned execution context of include/fosvos_hip.h: every event the multi-stream network calls order their
+// streams with.  Created whole by fosvos_ctx_create (util.hip), never grown later.
+constexpr int kFosvosVggEvents = 25, kFosvosResnetEvents = 12;
+struct fosvos_ctx {
+    uint32_t magic;                       // 'FCTX' while alive
+    int device;
+    hipEvent_t vgg_ev[kFosvosVggEvents];
+    hipEvent_t resnet_ev[kFosvosResnetEvents];
+    bool buckets_recorded;                // the last fosvos_vgg_backward on this context published its gradient buckets
+};
+constexpr uint32_t kFosvosCtxMagic = 0x58544346u;
+namespace fosvos {
+inline int ctx_check(const fosvos_ctx *ctx, const char *who) {
+    FOSVOS_REQUIRE(ctx != nullptr, FOSVOS_E_ARG, "%s: null context (fosvos_ctx_create)", who);
+    FOSVOS_REQUIRE(ctx->magic == kFosvosCtxMagic, FOSVOS_E_ARG, "%s: not a live fosvos_ctx", who);
+    return FOSVOS_OK;
+}
+
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
 

@@ -180,6 +180,19 @@ __global__ __launch_bounds__(256) void k_first_fwd(const float *__restrict__ fra
 
 }  // namespace
 
+namespace {
+constexpr int kFirstMaxWorkgroups = 1024;  // persistent workgroups (the weight operands are built once per workgroup): four per CU
+}
+extern "C" int fosvos_conv3x3_first_plan(int N, int H, int W, int *tiles, int *workgroups) {
+    FOSVOS_REQUIRE(tiles && workgroups, FOSVOS_E_ARG, "conv3x3_first_plan: null output");
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0, FOSVOS_E_SHAPE, "conv3x3_first_plan: bad shape N=%d H=%d W=%d", N, H, W);
+    const int64_t t = cdiv(W, TW) * cdiv(H, TH) * N;
+    FOSVOS_REQUIRE(t < 0x7fffffffLL, FOSVOS_E_SHAPE, "conv3x3_first_plan: too many tiles");
+    *tiles = (int)t;
+    *workgroups = (int)std::min<int64_t>(t, kFirstMaxWorkgroups);
+    return FOSVOS_OK;
+}
+
 extern "C" int fosvos_conv3x3_first_fwd(const float *frame, const float *w, const float *bias, uint16_t *y, int N,
                                         int H, int W, int Co, int device, void *stream) {
     FOSVOS_REQUIRE(frame && w && bias && y, FOSVOS_E_ARG, "conv3x3_first_fwd: null pointer");
@@ -190,8 +203,7 @@ extern "C" int fosvos_conv3x3_first_fwd(const float *frame, const float *w, cons
     const int tiles_x = (int)cdiv(W, TW), tiles_y = (int)cdiv(H, TH);
     const int64_t tiles = (int64_t)tiles_x * tiles_y * N;
     FOSVOS_REQUIRE(tiles < 0x7fffffffLL, FOSVOS_E_SHAPE, "conv3x3_first_fwd: too many tiles");
-    // persistent workgroups (the weight operands are built once per workgroup): four per CU
-    const unsigned grid = (unsigned)std::min<int64_t>(tiles, 1024);
+    const unsigned grid = (unsigned)std::min<int64_t>(tiles, kFirstMaxWorkgroups);
     FOSVOS_PROF("k_first_fwd", stream, 2.0 * N * H * W * 27 * Co);
     hipLaunchKernelGGL(k_first_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, frame, w, bias, y, N, H, W, tiles_x,
                        tiles_y);

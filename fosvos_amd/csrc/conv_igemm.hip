@@ -768,6 +768,28 @@ extern "C" size_t fosvos_conv3x3_workspace_bytes(int N, int H, int W, int in_ch,
     return make_plan(N, H, W, in_ch, out_ch).workspace_bytes;
 }
 
+extern "C" int fosvos_conv3x3_plan(int N, int H, int W, int in_ch, int out_ch, fosvos_conv3x3_plan_info *out) {
+    FOSVOS_REQUIRE(out, FOSVOS_E_ARG, "conv3x3_plan: null output");
+    FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && in_ch > 0 && out_ch > 0 && (out_ch % 64 == 0 || out_ch == 32 || out_ch == 16),
+                   FOSVOS_E_SHAPE, "conv3x3_plan: bad shape N=%d H=%d W=%d in=%d out=%d", N, H, W, in_ch, out_ch);
+    const ConvPlan p = make_plan(N, H, W, in_ch, out_ch);
+    int th = 0, tw = 0, bn = 0;
+    switch (p.tile) {
+        case kBig: th = TileBig::TH; tw = TileBig::TW; bn = TileBig::BN; break;
+        case kSquare: th = TileSquare::TH; tw = TileSquare::TW; bn = TileSquare::BN; break;
+        case kMid: th = TileMid::TH; tw = TileMid::TW; bn = TileMid::BN; break;
+        case kSmall: th = TileSmall::TH; tw = TileSmall::TW; bn = TileSmall::BN; break;
+        case kSide: th = TileSide::TH; tw = TileSide::TW; bn = TileSide::BN; break;
+        case kSideS: th = TileSideS::TH; tw = TileSideS::TW; bn = TileSideS::BN; break;
+        case kHalf: th = TileHalf::TH; tw = TileHalf::TW; bn = TileHalf::BN; break;
+        case kHalfS: th = TileHalfS::TH; tw = TileHalfS::TW; bn = TileHalfS::BN; break;
+    }
+    out->tile_h = th; out->tile_w = tw; out->tile_co = bn;
+    out->k_splits = p.k_splits;
+    out->workgroups = (int)(cdiv(W, tw) * cdiv(H, th) * N * (out_ch / bn));
+    return FOSVOS_OK;
+}
+
 extern "C" int fosvos_conv3x3_fwd(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int N, int H,
                                   int W, int Ci, int Co, unsigned flags, void *workspace, size_t workspace_bytes,
                                   int device, void *stream) {

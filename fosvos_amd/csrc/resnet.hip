@@ -14,7 +14,6 @@
 // Padded channels hold exact zeros everywhere (zero weights and bias), so no kernel ever masks a channel.
 #include "common.hpp"
 
-#include <mutex>
 
 using namespace fosvos;
 
@@ -1077,31 +1076,13 @@ extern "C" size_t fosvos_resnet_arena_bytes(const fosvos_resnet_net *net, int N,
     return resnet_layout(net, N, H, W, &L) ? 0 : L.total;
 }
 
-namespace {
-constexpr int kResnetEvents = 12;  // 0: fork point, 1: downsample done, 2..5: side map s done, 6..9: side conv s may start
-struct ResnetEvents {
-    bool ready = false;
-    hipEvent_t ev[kResnetEvents];
-};
-ResnetEvents g_resnet_events[16];
-std::mutex g_resnet_events_mutex;
-
-int resnet_events(int device, hipEvent_t **out) {
-    FOSVOS_REQUIRE(device >= 0 && device < 16, FOSVOS_E_ARG, "resnet_forward: device %d", device);
-    std::lock_guard<std::mutex> lock(g_resnet_events_mutex);
-    ResnetEvents &p = g_resnet_events[device];
-    if (!p.ready) {
-        for (int i = 0; i < kResnetEvents; ++i) FOSVOS_HIP_CHECK(hipEventCreateWithFlags(&p.ev[i], hipEventDisableTiming));
-        p.ready = true;
-    }
-    *out = p.ev;
-    return 0;
-}
-}  // namespace
+// events of the caller's context (fosvos_ctx::resnet_ev) when an aux_stream is given:
+// 0: fork point, 1: downsample done, 2..5: side map s done, 6..9: side conv s may start
+static_assert(kFosvosResnetEvents == 12, "event slots of resnet_forward");
 
 extern "C" int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *frame, int N, int H, int W, void *arena,
                                      size_t arena_bytes, float *fused, float *const side_out[4], int device,
-                                     void *stream, void *aux_stream) {
+                                     void *stream, fosvos_ctx *ctx, void *aux_stream) {
     ResnetLayout L;
     if (int rc = resnet_layout(net, N, H, W, &L)) return rc;
     FOSVOS_REQUIRE(frame && arena && fused, FOSVOS_E_ARG, "resnet_forward: null pointer");
@@ -1112,7 +1093,10 @@ extern "C" int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *
     const bool par = aux_stream != nullptr && aux_stream != stream;
     hipEvent_t *ev = nullptr;
     if (par) {
-        if (int rc = resnet_events(device, &ev)) return rc;
+        if (int rc = ctx_check(ctx, "resnet_forward (aux_stream given)")) return rc;
+        FOSVOS_REQUIRE(ctx->device == device, FOSVOS_E_ARG, "resnet_forward: context of device %d used on device %d",
+                       ctx->device, device);
+        ev = ctx->resnet_ev;
     }
     char *base = reinterpret_cast<char *>(((uintptr_t)arena + 255) & ~(uintptr_t)255);
     uint16_t *first = reinterpret_cast<uint16_t *>(base);

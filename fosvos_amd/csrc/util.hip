@@ -14,6 +14,7 @@ extern "C" int fosvos_abi_version(void) { return FOSVOS_ABI_VERSION; }
 // Timing events around every kernel launch, on the stream the kernel is launched on (the two-stream backward has two).
 // Events exist only between fosvos_profile_start and fosvos_profile_stop; nothing is allocated otherwise.
 #include <mutex>
+#include <new>
 #include <vector>
 namespace fosvos {
 bool g_prof_on = false;
@@ -104,6 +105,46 @@ extern "C" int fosvos_profile_stop(int device, fosvos_profile_record *out, int c
     *n_out = n;
     return rc;
 }
+// ------------------------------------------------------------------------------------------ execution context
+extern "C" int fosvos_ctx_create(int device, fosvos_ctx **ctx_out) {
+    FOSVOS_REQUIRE(ctx_out, FOSVOS_E_ARG, "ctx_create: null output");
+    *ctx_out = nullptr;
+    FOSVOS_REQUIRE(device >= 0, FOSVOS_E_ARG, "ctx_create: device %d", device);
+    FOSVOS_ENTER(device);
+    fosvos_ctx *c = new (std::nothrow) fosvos_ctx();
+    FOSVOS_REQUIRE(c, FOSVOS_E_ARG, "ctx_create: out of host memory");
+    c->device = device;
+    c->buckets_recorded = false;
+    hipEvent_t *all[2] = {c->vgg_ev, c->resnet_ev};
+    const int count[2] = {kFosvosVggEvents, kFosvosResnetEvents};
+    for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < count[k]; ++i)
+            if (hipEventCreateWithFlags(&all[k][i], hipEventDisableTiming) != hipSuccess) {
+                for (int k2 = 0; k2 <= k; ++k2)
+                    for (int j = 0; j < (k2 < k ? count[k2] : i); ++j) (void)hipEventDestroy(all[k2][j]);
+                delete c;
+                return fail(FOSVOS_E_HIP, "ctx_create: hipEventCreateWithFlags failed on device %d", device);
+            }
+    c->magic = kFosvosCtxMagic;
+    *ctx_out = c;
+    return FOSVOS_OK;
+}
+
+extern "C" int fosvos_ctx_destroy(fosvos_ctx *ctx) {
+    if (!ctx) return FOSVOS_OK;
+    if (int rc = ctx_check(ctx, "ctx_destroy")) return rc;
+    FOSVOS_ENTER(ctx->device);
+    ctx->magic = 0;
+    for (int i = 0; i < kFosvosVggEvents; ++i) (void)hipEventDestroy(ctx->vgg_ev[i]);
+    for (int i = 0; i < kFosvosResnetEvents; ++i) (void)hipEventDestroy(ctx->resnet_ev[i]);
+    delete ctx;
+    return FOSVOS_OK;
+}
+
+extern "C" int fosvos_ctx_device(const fosvos_ctx *ctx) {
+    return (ctx && ctx->magic == kFosvosCtxMagic) ? ctx->device : -1;
+}
+
 extern "C" const char *fosvos_last_error(void) { return fosvos::g_err; }
 extern "C" const char *fosvos_build_arch(void) { return "gfx950"; }
 

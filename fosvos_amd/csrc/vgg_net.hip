@@ -7,8 +7,6 @@
 // marshalling and allocator time (1.8 ms/step - as much as the GPU needs); from C++ a launch costs ~3 us.
 #include <stdlib.h>
 
-#include <mutex>
-
 #include "common.hpp"
 
 using namespace fosvos;
@@ -84,34 +82,14 @@ Arena make_arena(int N, int H, int W) {
     return a;
 }
 
-// ---- the library's only persistent state: timing-disabled events for the two-stream backward
+// ---- events of the caller's context (fosvos_ctx::vgg_ev): timing-disabled, for the two-stream passes
 // 13 conv-output gradients + head + fork + join + d_side[0..2] (aux -> main) + gradient-bucket events: stage 5, 4, 3 (19..21)
 // and "everything" (22) + "stage 2's weight gradients are queued" (23) + "the main stream's share of the tail is done" (24)
-constexpr int kNEvents = 25;
+static_assert(kFosvosVggEvents == 25, "event slots below");
 constexpr int kBucketFinalEvent = 22;  // every gradient the wgrad stream produces is final
 constexpr int kStage2WgradEvent = 23;  // stage 2's weight-gradient kernels are queued on the wgrad stream
 constexpr int kMainTailEvent = 24;     // the reductions offloaded to the main stream's end are done
 constexpr int kBucketEvent0 = 19;
-struct EventPool {
-    hipEvent_t ev[kNEvents];
-    bool ready = false;
-    bool buckets_recorded = false;  // the last backward on this device published its gradient buckets
-};
-EventPool g_events[16];  // per device
-std::mutex g_events_mutex;
-
-int get_events(int device, hipEvent_t **out, EventPool **pool_out = nullptr) {
-    FOSVOS_REQUIRE(device >= 0 && device < 16, FOSVOS_E_ARG, "vgg_backward: device index %d out of range", device);
-    std::lock_guard<std::mutex> lock(g_events_mutex);
-    EventPool &p = g_events[device];
-    if (!p.ready) {
-        for (int i = 0; i < kNEvents; ++i) FOSVOS_HIP_CHECK(hipEventCreateWithFlags(&p.ev[i], hipEventDisableTiming));
-        p.ready = true;
-    }
-    *out = p.ev;
-    if (pool_out) *pool_out = &p;
-    return FOSVOS_OK;
-}
 
 #define FOSVOS_TRY(expr)          \
     do {                          \
@@ -137,9 +115,9 @@ extern "C" size_t fosvos_vgg_arena_bytes(int N, int H, int W) {
 // aux_stream (optional): the four side_prep convs (16 output channels: memory-bound, 120 us per five 480x854 frames) run on
 // it, beside the backbone's MFMA-bound convs of the NEXT stage, instead of between them; `stream` waits for them in front of
 // the head.  The caller sees single-stream semantics on `stream`.
-extern "C" int fosvos_vgg_forward_streams(const fosvos_vgg_weights *w, const float *frame, int N, int H, int W, void *arena,
-                                          size_t arena_bytes, float *fused, float *const side_out[4], int device,
-                                          void *stream, void *aux_stream) {
+namespace {
+int forward_impl(hipEvent_t *ev, const fosvos_vgg_weights *w, const float *frame, int N, int H, int W, void *arena,
+                 size_t arena_bytes, float *fused, float *const side_out[4], int device, void *stream, void *aux_stream) {
     const Arena a = make_arena(N, H, W);
     FOSVOS_TRY(check_net(w, frame, arena, N, H, W, arena_bytes, a, "vgg_forward"));
     FOSVOS_REQUIRE(fused, FOSVOS_E_ARG, "vgg_forward: null output");
@@ -147,14 +125,9 @@ extern "C" int fosvos_vgg_forward_streams(const fosvos_vgg_weights *w, const flo
     auto act = [&](int c) { return reinterpret_cast<uint16_t *>(base + a.act[c]); };
     void *ws = base + a.ws;
     hipStream_t sm = (hipStream_t)stream;
-    const bool par = aux_stream != nullptr && aux_stream != stream;
+    const bool par = ev != nullptr && aux_stream != nullptr && aux_stream != stream;
     hipStream_t sa = par ? (hipStream_t)aux_stream : sm;
-    hipEvent_t *ev = nullptr;
-    if (par) {
-        EventPool *pool = nullptr;
-        FOSVOS_ENTER(device);
-        FOSVOS_TRY(get_events(device, &ev, &pool));
-    }
+    if (par) FOSVOS_ENTER(device);
     const uint16_t *x = nullptr;
     for (int c = 0; c < kNConv; ++c) {
         const int s = kStageOf[c];
@@ -202,16 +175,27 @@ extern "C" int fosvos_vgg_forward_streams(const fosvos_vgg_weights *w, const flo
     return fosvos_head_fwd(side, hs, wsz, w->filt, w->filt1, w->dsn_w, w->dsn_b, w->fuse_w, w->fuse_b, fused, side_out, N, H,
                            W, device, stream);
 }
+}  // namespace
+
+extern "C" int fosvos_vgg_forward_streams(fosvos_ctx *ctx, const fosvos_vgg_weights *w, const float *frame, int N, int H,
+                                          int W, void *arena, size_t arena_bytes, float *fused, float *const side_out[4],
+                                          void *stream, void *aux_stream) {
+    FOSVOS_TRY(ctx_check(ctx, "vgg_forward_streams"));
+    return forward_impl(ctx->vgg_ev, w, frame, N, H, W, arena, arena_bytes, fused, side_out, ctx->device, stream, aux_stream);
+}
 
 extern "C" int fosvos_vgg_forward(const fosvos_vgg_weights *w, const float *frame, int N, int H, int W, void *arena,
                                   size_t arena_bytes, float *fused, float *const side_out[4], int device,
                                   void *stream) {
-    return fosvos_vgg_forward_streams(w, frame, N, H, W, arena, arena_bytes, fused, side_out, device, stream, nullptr);
+    return forward_impl(nullptr, w, frame, N, H, W, arena, arena_bytes, fused, side_out, device, stream, nullptr);
 }
 
-extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg_grads *g, const float *frame, int N,
-                                   int H, int W, void *arena, size_t arena_bytes, const float *d_fused,
-                                   const float *const d_side_out[4], int device, void *stream, void *aux_stream) {
+extern "C" int fosvos_vgg_backward(fosvos_ctx *ctx, const fosvos_vgg_weights *w, const fosvos_vgg_grads *g,
+                                   const float *frame, int N, int H, int W, void *arena, size_t arena_bytes,
+                                   const float *d_fused, const float *const d_side_out[4], void *stream,
+                                   void *aux_stream) {
+    FOSVOS_TRY(ctx_check(ctx, "vgg_backward"));
+    const int device = ctx->device;
     const Arena a = make_arena(N, H, W);
     FOSVOS_TRY(check_net(w, frame, arena, N, H, W, arena_bytes, a, "vgg_backward"));
     FOSVOS_REQUIRE(g, FOSVOS_E_ARG, "vgg_backward: null gradient table");
@@ -231,8 +215,7 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
     hipStream_t sm = (hipStream_t)stream;
     const bool par = aux_stream != nullptr && aux_stream != stream;
     hipStream_t sa = par ? (hipStream_t)aux_stream : sm;
-    hipEvent_t *ev = nullptr;
-    EventPool *pool = nullptr;
+    hipEvent_t *ev = ctx->vgg_ev;
     const bool buckets = g->bucket_events != 0;
     // the weight gradients of stages 1-2 come last; after the cycle's LAST backward pass nothing runs beside them
     const bool tail = g->last_pass_of_cycle != 0;
@@ -243,12 +226,8 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
     // last outputs) and the slab reduction of stage 2 (behind an event the wgrad stream records after stage 2's kernels).
     static const bool offload_on = !(getenv("FOSVOS_TAIL_OFFLOAD") && atoi(getenv("FOSVOS_TAIL_OFFLOAD")) == 0);
     const bool offload = tail && aux_stream != nullptr && aux_stream != stream && offload_on;
-    if (par || buckets) {
-        FOSVOS_ENTER(device);
-        FOSVOS_TRY(get_events(device, &ev, &pool));
-        std::lock_guard<std::mutex> lock(g_events_mutex);
-        pool->buckets_recorded = false;
-    }
+    FOSVOS_ENTER(device);
+    ctx->buckets_recorded = false;
     if (par) {
         // fork: the wgrad stream may not run ahead of what `stream` has queued (the forward pass, the loss)
         FOSVOS_HIP_CHECK(hipEventRecord(ev[14], sm));
@@ -357,8 +336,7 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
     if (buckets) FOSVOS_HIP_CHECK(hipEventRecord(ev[kMainTailEvent], sm));  // (also covers the head's main-stream share)
     if (buckets) {
         FOSVOS_HIP_CHECK(hipEventRecord(ev[kBucketFinalEvent], sa));  // buckets 3 and 4: everything the wgrad stream owes
-        std::lock_guard<std::mutex> lock(g_events_mutex);
-        pool->buckets_recorded = true;
+        ctx->buckets_recorded = true;
     }
     if (par && !g->defer_join) {  // join: everything after this call on `stream` sees the weight gradients
         FOSVOS_HIP_CHECK(hipEventRecord(ev[15], sa));
@@ -367,17 +345,13 @@ extern "C" int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg
     return FOSVOS_OK;
 }
 
-extern "C" int fosvos_vgg_grad_bucket_wait(int device, int bucket, void *stream) {
+extern "C" int fosvos_vgg_grad_bucket_wait(fosvos_ctx *ctx, int bucket, void *stream) {
+    FOSVOS_TRY(ctx_check(ctx, "vgg_grad_bucket_wait"));
     FOSVOS_REQUIRE(bucket >= 0 && bucket < 5, FOSVOS_E_ARG, "vgg_grad_bucket_wait: bucket %d not in 0..4", bucket);
-    FOSVOS_ENTER(device);
-    hipEvent_t *ev = nullptr;
-    EventPool *pool = nullptr;
-    FOSVOS_TRY(get_events(device, &ev, &pool));
-    {
-        std::lock_guard<std::mutex> lock(g_events_mutex);
-        FOSVOS_REQUIRE(pool->buckets_recorded, FOSVOS_E_ARG,
-                       "vgg_grad_bucket_wait: the last fosvos_vgg_backward on device %d did not set grads.bucket_events", device);
-    }
+    FOSVOS_ENTER(ctx->device);
+    FOSVOS_REQUIRE(ctx->buckets_recorded, FOSVOS_E_ARG,
+                   "vgg_grad_bucket_wait: the last fosvos_vgg_backward on this context did not set grads.bucket_events");
+    hipEvent_t *ev = ctx->vgg_ev;
     if (bucket < 3) {
         FOSVOS_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ev[kBucketEvent0 + bucket], 0));
     } else {  // the tail buckets: the wgrad stream's last reduction AND what the pass left at the end of its main stream

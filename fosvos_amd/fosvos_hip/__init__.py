@@ -15,7 +15,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 CONV_RELU = 1
 CONV_OUT_F32 = 2
 
@@ -46,6 +46,11 @@ class VggGrads(ctypes.Structure):
     _fields_ = [("conv_w", _P13), ("conv_b", _P13), ("side_w", _P4), ("side_b", _P4),
                 ("dsn_w", c_void_p), ("dsn_b", c_void_p), ("fuse_w", c_void_p), ("fuse_b", c_void_p),
                 ("accumulate", c_int), ("defer_join", c_int), ("bucket_events", c_int), ("last_pass_of_cycle", c_int)]
+
+class Conv3x3PlanInfo(ctypes.Structure):
+    """fosvos_conv3x3_plan_info."""
+    _fields_ = [("tile_h", c_int), ("tile_w", c_int), ("tile_co", c_int), ("k_splits", c_int), ("workgroups", c_int)]
+
 
 class ProfileRecord(ctypes.Structure):
     """fosvos_profile_record."""
@@ -82,6 +87,11 @@ SIGNATURES = {
     "fosvos_abi_version": (c_int, []),
     "fosvos_last_error": (c_char_p, []),
     "fosvos_build_arch": (c_char_p, []),
+    "fosvos_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "fosvos_ctx_destroy": (c_int, [c_void_p]),
+    "fosvos_ctx_device": (c_int, [c_void_p]),
+    "fosvos_conv3x3_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(Conv3x3PlanInfo)]),
+    "fosvos_conv3x3_first_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "fosvos_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fosvos_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fosvos_nhwc_f32_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -152,17 +162,17 @@ SIGNATURES = {
                                        POINTER(c_void_p), c_int, c_int, c_int, c_int, c_void_p]),
     "fosvos_resnet_arena_bytes": (c_size_t, [POINTER(ResnetNet), c_int, c_int, c_int]),
     "fosvos_resnet_forward": (c_int, [POINTER(ResnetNet), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
-                                      POINTER(c_void_p), c_int, c_void_p, c_void_p]),
+                                      POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p]),
     "fosvos_vgg_arena_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "fosvos_vgg_grad_bucket_wait": (c_int, [c_int, c_int, c_void_p]),
+    "fosvos_vgg_grad_bucket_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "fosvos_profile_start": (c_int, [c_int, c_int]),
     "fosvos_profile_stop": (c_int, [c_int, POINTER(ProfileRecord), c_int, POINTER(c_int)]),
     "fosvos_vgg_forward": (c_int, [POINTER(VggWeights), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                    POINTER(c_void_p), c_int, c_void_p]),
-    "fosvos_vgg_forward_streams": (c_int, [POINTER(VggWeights), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
-                                   POINTER(c_void_p), c_int, c_void_p, c_void_p]),
-    "fosvos_vgg_backward": (c_int, [POINTER(VggWeights), POINTER(VggGrads), c_void_p, c_int, c_int, c_int, c_void_p,
-                                    c_size_t, c_void_p, POINTER(c_void_p), c_int, c_void_p, c_void_p]),
+    "fosvos_vgg_forward_streams": (c_int, [c_void_p, POINTER(VggWeights), c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
+                                           c_void_p, POINTER(c_void_p), c_void_p, c_void_p]),
+    "fosvos_vgg_backward": (c_int, [c_void_p, POINTER(VggWeights), POINTER(VggGrads), c_void_p, c_int, c_int, c_int, c_void_p,
+                                    c_size_t, c_void_p, POINTER(c_void_p), c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -218,6 +228,27 @@ class LaunchProfile:
         self.records = {buf[i].name.decode(): {"launches": buf[i].launches, "ms": buf[i].ms, "flops": buf[i].flops}
                         for i in range(n.value)}
         return False
+
+
+class Context:
+    """A caller-owned fosvos_ctx (include/fosvos_hip.h): the inter-stream events of one model's multi-stream passes and
+    its gradient-bucket state.  One per model and device; destroyed with its owner."""
+
+    def __init__(self, device: int):
+        h = c_void_p()
+        check(lib().fosvos_ctx_create(int(device), ctypes.byref(h)), "ctx_create")
+        self.handle, self.device = h, int(device)
+
+    def close(self) -> None:
+        h, self.handle = self.handle, None
+        if h is not None and _lib is not None:
+            _lib.fosvos_ctx_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: the process is going away with its events
+            pass
 
 
 def ptr_array4(ptrs) -> "ctypes.Array":

@@ -277,7 +277,7 @@ def backward(P: Dict[str, torch.Tensor], packs: PackedWeights, sv: "Saved", d_ou
 import ctypes  # noqa: E402
 import os  # noqa: E402
 
-from . import VggGrads, VggWeights, check, lib, ptr_array4  # noqa: E402
+from . import Context, VggGrads, VggWeights, check, lib, ptr_array4  # noqa: E402
 
 USE_NATIVE_LOOP = os.environ.get("FOSVOS_PY_ENGINE", "0") != "1"  # debugging switch: Python-driven per-op loop
 
@@ -290,6 +290,7 @@ class ArenaPool:
     def __init__(self) -> None:
         self._free: Dict[Tuple[int, int, int, int], List[torch.Tensor]] = {}
         self._aux: Dict[int, "torch.cuda.Stream"] = {}
+        self._ctx: Dict[int, "Context"] = {}  # the model's execution context per device (events of its two-stream passes)
         self._pending: List[Tuple[int, int, int, torch.Tensor]] = []  # arenas still read by deferred wgrad kernels
 
     def aux_stream(self, device_index: int) -> int:
@@ -302,6 +303,13 @@ class ArenaPool:
             st = torch.cuda.Stream(device=device_index)
             self._aux[device_index] = st
         return st.cuda_stream
+
+    def ctx(self, device_index: int):
+        """Handle of this model's fosvos_ctx on `device_index` (created on first use, destroyed with the pool)."""
+        c = self._ctx.get(device_index)
+        if c is None:
+            c = self._ctx[device_index] = Context(device_index)
+        return c.handle
 
     def take(self, n: int, h: int, w: int, device: torch.device) -> torch.Tensor:
         key = (n, h, w, device.index if device.index is not None else torch.cuda.current_device())
@@ -387,8 +395,12 @@ def native_forward(P, packs, pool: ArenaPool, x: torch.Tensor, with_side_out: bo
     # five-frame training pass; FOSVOS_FWD_AUX=0: one stream).  A single frame stays on one stream: its kernels are too
     # short for the four event pairs to pay (inference protocol: 0.586 vs 0.564 ms per frame).
     aux = pool.aux_stream(idx) if N >= 2 and os.environ.get("FOSVOS_FWD_AUX", "1") != "0" else 0
-    check(lib().fosvos_vgg_forward_streams(ctypes.byref(w), x.data_ptr(), N, H, W, ap, an, fused.data_ptr(), so, idx,
-                                           torch.cuda.current_stream(idx).cuda_stream, aux or None), "vgg_forward")
+    if aux:
+        check(lib().fosvos_vgg_forward_streams(pool.ctx(idx), ctypes.byref(w), x.data_ptr(), N, H, W, ap, an, fused.data_ptr(),
+                                               so, torch.cuda.current_stream(idx).cuda_stream, aux), "vgg_forward_streams")
+    else:
+        check(lib().fosvos_vgg_forward(ctypes.byref(w), x.data_ptr(), N, H, W, ap, an, fused.data_ptr(), so, idx,
+                                       torch.cuda.current_stream(idx).cuda_stream), "vgg_forward")
     ops._pe(t0, "vgg_forward", 2.0 * 129.114e9 * N * H * W / (480 * 854), 0.0)
     if not keep:
         pool.give(N, H, W, arena)
@@ -451,8 +463,8 @@ def native_backward(P, packs, saved, d_outs, inplace: bool, defer_join: bool = F
     # the dsn scratch is overwritten, never accumulated, by a separate flag-free path: run with accumulate for the
     # parameter buffers and add the scratch afterwards
     t0 = ops._pb()
-    check(lib().fosvos_vgg_backward(ctypes.byref(w), ctypes.byref(g), x.data_ptr(), N, H, W, ap, an,
-                                    d_fused.data_ptr() if d_fused is not None else None, dso, idx,
+    check(lib().fosvos_vgg_backward(packs.arenas.ctx(idx), ctypes.byref(w), ctypes.byref(g), x.data_ptr(), N, H, W, ap, an,
+                                    d_fused.data_ptr() if d_fused is not None else None, dso,
                                     torch.cuda.current_stream(idx).cuda_stream, aux or None),
           "vgg_backward")
     ops._pe(t0, "vgg_backward", 2.0 * (2 * 129.114e9 - 0.708e9) * N * H * W / (480 * 854), 0.0)

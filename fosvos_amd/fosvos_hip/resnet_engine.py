@@ -16,7 +16,7 @@ import torch.nn as nn
 import ctypes
 import os
 
-from . import Conv2dDesc, ResnetBlock, ResnetNet, check, lib, ops, ptr_array4
+from . import Context, Conv2dDesc, ResnetBlock, ResnetNet, check, lib, ops, ptr_array4
 
 
 def use_mfma() -> bool:
@@ -310,7 +310,7 @@ def forward(net: nn.Module, plan: ResnetPlan, x: torch.Tensor) -> List[torch.Ten
     with_side = bool(getattr(net, "compute_side_outputs", True))
     outs = [torch.empty((n, 1, h, w) if with_side or i == 4 else (0,), dtype=torch.float32, device=x.device) for i in range(5)]
     dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
-    aux = None
+    aux = ctx = None
     # FOSVOS_RESNET_AUX=1 issues the side_prep / downsample convs on a second stream beside the trunk.  Off by default:
     # measured at 1080p it LOSES 0.09-0.12 ms per frame on every net (the ~20 cross-stream event waits cost more than the
     # seven small kernels they take off the chain).
@@ -318,8 +318,11 @@ def forward(net: nn.Module, plan: ResnetPlan, x: torch.Tensor) -> List[torch.Ten
         if plan.aux is None or plan.aux.device != x.device:
             plan.aux = torch.cuda.Stream(device=x.device)
         aux = plan.aux.cuda_stream
+        if getattr(plan, "ctx", None) is None or plan.ctx.device != dev:
+            plan.ctx = Context(dev)  # the events that order the two streams belong to this model's plan
+        ctx = plan.ctx.handle
     check(L.fosvos_resnet_forward(ctypes.byref(plan.c_net), x.data_ptr(), n, h, w, plan.arena.data_ptr(),
                                   plan.arena.numel(), outs[4].data_ptr(),
                                   ptr_array4([o.data_ptr() if with_side else None for o in outs[:4]]), dev,
-                                  torch.cuda.current_stream(dev).cuda_stream, aux), "resnet_forward")
+                                  torch.cuda.current_stream(dev).cuda_stream, ctx, aux), "resnet_forward")
     return outs

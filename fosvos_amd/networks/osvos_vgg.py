@@ -110,6 +110,12 @@ class OSVOS_VGG(nn.Module):
         self._packs.publish_grad_buckets = bool(value)
 
     @property
+    def publishes_grad_buckets(self):
+        """Whether backward passes of this module can publish gradient buckets at all: only the native layer loop records
+        the bucket events (the per-op Python engine behind FOSVOS_PY_ENGINE=1 does not)."""
+        return bool(engine.USE_NATIVE_LOOP)
+
+    @property
     def last_pass_of_cycle(self):
         return getattr(self._packs, "last_pass_of_cycle", False)
 
@@ -121,13 +127,14 @@ class OSVOS_VGG(nn.Module):
 
     def wait_grad_bucket(self, bucket, stream=None):
         """Make `stream` (default: the current one) wait for gradient bucket `bucket` (``parallel.VGG_BUCKETS`` order) of
-        the last backward pass run with ``publish_grad_buckets``; returns at once on the host."""
+        the last backward pass OF THIS MODULE run with ``publish_grad_buckets`` (the events live in the module's own
+        fosvos_ctx, so another model training on the same device never interferes); returns at once on the host."""
         import torch
         from fosvos_hip import check, lib
         dev = next(self.parameters()).device
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
         st = stream if stream is not None else torch.cuda.current_stream(idx)
-        check(lib().fosvos_vgg_grad_bucket_wait(idx, int(bucket), st.cuda_stream), "vgg_grad_bucket_wait")
+        check(lib().fosvos_vgg_grad_bucket_wait(self._packs.arenas.ctx(idx), int(bucket), st.cuda_stream), "vgg_grad_bucket_wait")
 
     def _ordered_params(self):
         """The 52 parameters in state_dict order, by direct attribute access (named_parameters() walks the whole
@@ -146,6 +153,7 @@ class OSVOS_VGG(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state.pop('_packs', None)  # whole-module pickles (NetworkProvider.save_model) carry no device caches
+        state.pop('_fosvos_flat_grads', None)  # ... nor a training loop's flat gradient buffer (parallel.FlatGrads.attach)
         state['compute_side_outputs'] = True        # ... and no loop-local switches (a snapshot taken inside _train)
         state['accumulate_grads_in_place'] = False
         return state

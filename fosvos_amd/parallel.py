@@ -116,13 +116,18 @@ class FlatGrads:
         # the engine never produces a gradient for them (the reference keeps them at lr 0), their slice stays zero.
         self.slices: List[Tuple[int, int]] = [(0, cur)]
         self.bucket_params: List[List[torch.nn.Parameter]] = [list(self.params)]  # the parameters inside each slice
+        # slice b holds bucket `bucket_ids[b]` of `buckets` (the index fosvos_vgg_grad_bucket_wait takes): a bucket without
+        # trainable parameters leaves no slice, so slice and bucket numbers differ as soon as a stage is frozen; slices of
+        # tensors outside every bucket (and the single slice of the unnamed form) wait for the pass's LAST bucket
+        self.bucket_ids: List[int] = [len(buckets) - 1]
         if names is not None:
             trainable = [n for n, p in zip(names, params) if p.requires_grad]
             ends = offs[1:] + [cur]
             self.slices = []
             self.bucket_params = []
+            self.bucket_ids = []
             covered = set()
-            for prefixes in buckets:
+            for bucket_id, prefixes in enumerate(buckets):
                 idx = [i for i, n in enumerate(trainable) if n.startswith(tuple(prefixes))]
                 if not idx:
                     continue
@@ -130,6 +135,7 @@ class FlatGrads:
                     raise ValueError(f"FlatGrads: bucket {prefixes} is not contiguous in parameter order")
                 self.slices.append((offs[idx[0]], ends[idx[-1]]))
                 self.bucket_params.append([self.params[i] for i in idx])
+                self.bucket_ids.append(bucket_id)
                 covered.update(idx)
             run: List[int] = []
             for i, n in enumerate(trainable + [None]):
@@ -138,6 +144,7 @@ class FlatGrads:
                 elif run:
                     self.slices.append((offs[run[0]], ends[run[-1]]))
                     self.bucket_params.append([self.params[i] for i in run])
+                    self.bucket_ids.append(len(buckets) - 1)
                     run = []
         self._works: list = []
 
@@ -187,15 +194,15 @@ class FlatGrads:
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
 
     def all_reduce_begin(self, wait_bucket: Optional[Callable[[int], None]] = None) -> None:
-        """One asynchronous SUM all-reduce per bucket, in completion order.  `wait_bucket(b)` is called right before
-        bucket b's collective is enqueued and must make the CURRENT stream wait for that bucket's gradients (on the
-        HIP path: fosvos_vgg_grad_bucket_wait on the communication stream); None = the current stream already
-        follows the whole backward pass."""
+        """One asynchronous SUM all-reduce per slice, in completion order.  `wait_bucket(id)` is called right before a
+        slice's collective is enqueued with the slice's NATIVE bucket id (`bucket_ids`) and must make the CURRENT stream
+        wait for that bucket's gradients (on the HIP path: fosvos_vgg_grad_bucket_wait on the communication stream);
+        None = the current stream already follows the whole backward pass."""
         if world_size() == 1:
             return
         for b, (lo, hi) in enumerate(self.slices):
             if wait_bucket is not None:
-                wait_bucket(b)
+                wait_bucket(self.bucket_ids[b])
             self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def all_reduce_wait(self, bucket: int) -> None:
@@ -241,7 +248,8 @@ class GradSync:
         net = self.net
         if hasattr(net, "publish_grad_buckets"):
             net.publish_grad_buckets = False
-        if self.flat.flat.is_cuda and hasattr(net, "wait_grad_bucket"):
+        # the bucket events exist only where the native backward pass recorded them (not under FOSVOS_PY_ENGINE=1)
+        if self.flat.flat.is_cuda and hasattr(net, "wait_grad_bucket") and getattr(net, "publishes_grad_buckets", True):
             if self._comm is None:
                 self._comm = torch.cuda.Stream(device=self.flat.flat.device)
             main = torch.cuda.current_stream(self.flat.flat.device)
@@ -254,6 +262,14 @@ class GradSync:
 
             with torch.cuda.stream(comm):
                 self.flat.all_reduce_begin(wait)
+        elif self.flat.flat.is_cuda:  # no per-bucket events: the communication stream follows the whole backward pass
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=self.flat.flat.device)
+            if hasattr(net, "join_gradients"):
+                net.join_gradients()
+            self._comm.wait_stream(torch.cuda.current_stream(self.flat.flat.device))
+            with torch.cuda.stream(self._comm):
+                self.flat.all_reduce_begin(None)
         else:
             self.flat.all_reduce_begin(None)
 

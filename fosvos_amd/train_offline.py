@@ -97,6 +97,11 @@ def _train(net_provider: NetworkProvider, data_loader_train, data_loader_test, o
     time_all_start = timeit.default_timer()
     for epoch in range(start_epoch, n_epochs):
         start_time = timeit.default_timer()
+        # a DistributedSampler (data-parallel loader) draws the same permutation every epoch unless it is told the epoch;
+        # the reference's shuffle=True loader draws a new order per epoch (src/util/io_helper.py:62-70)
+        sampler = getattr(data_loader_train, 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):
+            sampler.set_epoch(epoch)
         running = torch.zeros(5, device=device)
         for index, minibatch in enumerate(data_loader_train):
             losses = _losses(net, minibatch)
@@ -104,6 +109,8 @@ def _train(net_provider: NetworkProvider, data_loader_train, data_loader_test, o
             loss = (1 - epoch / n_epochs) * sum(losses[:-1]) + losses[-1]
 
             if index % n_samples_train == n_samples_train - 1:
+                if world > 1:  # every rank holds its shards' part of the batch losses: the logged value is their sum
+                    torch.distributed.all_reduce(running, op=torch.distributed.ReduceOp.SUM)
                 vals = (running / n_samples_train).tolist()  # one device->host sync per epoch
                 loss_train.append(vals[-1])
                 losses_train.append(vals)  # all five deeply supervised losses of the epoch

@@ -121,15 +121,16 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     sync = parallel.GradSync(net, flat)
 
     # on the GPU the optimizer step is split by gradient bucket (see run_group); FOSVOS_SPLIT_STEP=0 = one step
-    early_buckets = [b for b in range(parallel.VGG_EARLY_BUCKETS) if b < len(flat.slices)]
-    split_step = (flat.flat.is_cuda and hasattr(net, 'wait_grad_bucket')
-                  and len(flat.slices) > parallel.VGG_EARLY_BUCKETS
-                  and hasattr(optimizer, '_tables') and os.environ.get('FOSVOS_SPLIT_STEP', '1') != '0')
+    # (slice indices of the flat buffer; flat.bucket_ids maps a slice to the native bucket its gradients are published as)
+    early_buckets = [b for b, bid in enumerate(flat.bucket_ids) if bid < parallel.VGG_EARLY_BUCKETS]
     late_buckets = [b for b in range(len(flat.slices)) if b not in early_buckets]
+    split_step = (flat.flat.is_cuda and hasattr(net, 'wait_grad_bucket') and bool(early_buckets) and bool(late_buckets)
+                  and getattr(net, 'publishes_grad_buckets', True)  # the native backward pass records the bucket events
+                  and hasattr(optimizer, '_tables') and os.environ.get('FOSVOS_SPLIT_STEP', '1') != '0')
     early_params = [p for b in early_buckets for p in flat.bucket_params[b]]
     early_ids = {id(p) for p in early_params}
     late_params = [p for group in optimizer.param_groups for p in group['params'] if id(p) not in early_ids]
-    early_prefixes = tuple(pre for b in early_buckets for pre in parallel.VGG_BUCKETS[b])
+    early_prefixes = tuple(pre for b in early_buckets for pre in parallel.VGG_BUCKETS[flat.bucket_ids[b]])
 
     n_samples = len(dataloader)
     loss_tr = []
@@ -251,7 +252,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
                     if world > 1:
                         sync.wait_bucket(b)
                     else:
-                        net.wait_grad_bucket(b)
+                        net.wait_grad_bucket(flat.bucket_ids[b])
                 optimizer.step(only=early_params, tag='early')
                 flat.zero(early_buckets)
                 net.prepack_weights(early_prefixes)

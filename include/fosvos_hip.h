@@ -15,7 +15,9 @@
  *   - every call is asynchronous on `stream` (a hipStream_t) of `device`; no implicit sync;
  *   - return 0 on success, a negative FOSVOS_E_* code otherwise; fosvos_last_error() gives a
  *     thread-local message.  Nothing aborts or throws across the ABI;
- *   - re-entrant; the device is selected on every call (autograd runs backward on another thread).
+ *   - re-entrant; the device is selected on every call (autograd runs backward on another thread);
+ *   - no hidden state: the only objects that outlive a call are the inter-stream events of the multi-stream network
+ *     calls, and those live in a caller-owned context (fosvos_ctx, one per model), never in the library.
  *
  * Tensor layouts
  *   frame   fp32 NCHW [N,3,H,W]                  (the reference's input layout)
@@ -35,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 11
+#define FOSVOS_ABI_VERSION 12
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -69,6 +71,20 @@ int fosvos_profile_stop(int device, fosvos_profile_record *out, int capacity, in
 const char *fosvos_last_error(void);
 /* Name of the gfx target the code object was built for ("gfx950"). */
 const char *fosvos_build_arch(void);
+
+/* ---- execution context ------------------------------------------------------------------------------------------
+ * The multi-stream network calls (fosvos_vgg_forward_streams, fosvos_vgg_backward, fosvos_resnet_forward with an
+ * aux_stream) order their streams with timing-disabled hipEvents, and fosvos_vgg_backward publishes its gradient
+ * buckets through such events.  They belong to a context the CALLER creates, owns and destroys - one per model (or per
+ * host thread that drives a model): two models trained from two host threads on one GPU never share an event, and
+ * fosvos_vgg_grad_bucket_wait refers to the last backward pass OF ITS CONTEXT, not "of the device".  A context is bound
+ * to one device; calls on one context must not overlap in time (one host thread at a time).  Nothing else in the
+ * library keeps mutable state between calls (immutable per-device kernel attributes aside).
+ * _destroy does not synchronise: the caller makes sure the streams are done with the events (as for any hipEvent). */
+typedef struct fosvos_ctx fosvos_ctx;
+int fosvos_ctx_create(int device, fosvos_ctx **ctx_out);
+int fosvos_ctx_destroy(fosvos_ctx *ctx);
+int fosvos_ctx_device(const fosvos_ctx *ctx); /* the device the context was created on, -1 for NULL */
 
 /* ---- layout helpers (test/debug plumbing and the model's input/feature export) -------------- */
 /* fp32 NCHW -> bf16 NHWC, channels zero-padded from C to Cpad (Cpad % 8 == 0, Cpad >= C). */
@@ -108,6 +124,9 @@ int fosvos_pack_conv3x3_weights_multi(const fosvos_pack_entry *entries, int n, i
  * replaces: stages[0][0..1] = Conv2d(3,64,3,pad=1)+ReLU (src/networks/osvos_vgg.py:92-93). */
 int fosvos_conv3x3_first_fwd(const float *frame, const float *w_oihw, const float *bias, uint16_t *y, int N, int H,
                              int W, int Co, int device, void *stream);
+/* Launch geometry of the above: 8 x 32-pixel tiles and the (persistent) workgroups that walk them; tiles > workgroups
+ * means every workgroup loops over several tiles with its double-buffered staging.  Host arithmetic only. */
+int fosvos_conv3x3_first_plan(int N, int H, int W, int *tiles, int *workgroups);
 /* dw[Co,3,3,3], db[Co] (fp32, overwritten) from the frame and dy[N,H,W,Co] bf16.  No dgrad: the
  * image needs no gradient.  workspace: fosvos_conv3x3_first_wgrad_workspace_bytes. */
 int fosvos_conv3x3_first_wgrad(const float *frame, const uint16_t *dy, float *dw_oihw, float *dbias, int N, int H,
@@ -149,6 +168,16 @@ int fosvos_conv3x3_fwd_pool(const uint16_t *x, const uint16_t *w_packed, const f
 /* Scratch for fwd/dgrad with `in_ch` contraction and `out_ch` output channels (split-K partial
  * slabs for layers whose pixel count alone cannot fill 256 CUs; 0 when none is needed). */
 size_t fosvos_conv3x3_workspace_bytes(int N, int H, int W, int in_ch, int out_ch);
+/* Which kernel instantiation fosvos_conv3x3_fwd / _fwd_pool / _dgrad launch for a shape (`in_ch` contraction, `out_ch`
+ * output channels): the pixel tile (tile_h x tile_w) x tile_co output channels of one workgroup, the K split count and the
+ * number of workgroups.  Pure host arithmetic (no device call); the parity tests use it to assert that the cases they run
+ * really select the instantiations the 480x854 step runs (k_conv3x3_igemm<Tile<tile_h, tile_w, tile_co, ..>>). */
+typedef struct fosvos_conv3x3_plan_info {
+    int tile_h, tile_w, tile_co;
+    int k_splits;
+    int workgroups; /* per K split */
+} fosvos_conv3x3_plan_info;
+int fosvos_conv3x3_plan(int N, int H, int W, int in_ch, int out_ch, fosvos_conv3x3_plan_info *out);
 /* dx = mask( dgrad(dy) ) + addend:  the same kernel run on the rotated/transposed filter image.
  *   dy       bf16 NHWC, Co_pad = roundup(Co,32) channels (Co = the forward op's OUTPUT channels)
  *   relu_src bf16 NHWC [N,H,W,Ci] or NULL: where relu_src <= 0 the computed gradient is zeroed
@@ -352,12 +381,12 @@ size_t fosvos_resnet_arena_bytes(const fosvos_resnet_net *net, int N, int H, int
 /* fused: [N,1,H,W] fp32; side_out: four [N,1,H,W] fp32 buffers or NULL.
  * aux_stream (a second hipStream_t of the same device, or NULL): when given, the kernels the trunk does not wait for
  * right away - each stage's side_prep conv and the 1x1 downsample convs - are issued on it beside the trunk's chain
- * (thin layers leave most of the chip idle), ordered by events (12 timing-disabled hipEvents per device, created on
- * first use); the caller sees ordinary single-stream semantics on `stream`.  Measured on MI355X at 1920x1080 this
+ * (thin layers leave most of the chip idle), ordered by events of `ctx` (required with an aux_stream, else it may be
+ * NULL); the caller sees ordinary single-stream semantics on `stream`.  Measured on MI355X at 1920x1080 this
  * costs 0.1 ms per frame more than it saves (cross-stream waits), so the shipped host passes NULL. */
 int fosvos_resnet_forward(const fosvos_resnet_net *net, const float *frame, int N, int H, int W, void *arena,
                           size_t arena_bytes, float *fused, float *const side_out[4], int device, void *stream,
-                          void *aux_stream);
+                          fosvos_ctx *ctx, void *aux_stream);
 
 /* ---- whole-network entry points ------------------------------------------------------------------
  * The reference drives ~60 torch.nn calls per forward from Python (src/networks/osvos_vgg.py:61-83) and
@@ -413,28 +442,28 @@ int fosvos_vgg_forward(const fosvos_vgg_weights *w, const float *frame, int N, i
                        size_t arena_bytes, float *fused, float *const side_out[4], int device, void *stream);
 /* The same pass with a second stream of the same device (or NULL = fosvos_vgg_forward): the four side_prep convs
  * (16 output channels, memory-bound) are issued on aux_stream beside the next stage's backbone convs; `stream` waits for
- * them (events of the pool described under fosvos_vgg_backward) in front of the head, so the caller sees single-stream
+ * them (events of `ctx`, whose device the call runs on) in front of the head, so the caller sees single-stream
  * semantics on `stream`.  Results are bit-identical to fosvos_vgg_forward. */
-int fosvos_vgg_forward_streams(const fosvos_vgg_weights *w, const float *frame, int N, int H, int W, void *arena,
-                               size_t arena_bytes, float *fused, float *const side_out[4], int device, void *stream,
+int fosvos_vgg_forward_streams(fosvos_ctx *ctx, const fosvos_vgg_weights *w, const float *frame, int N, int H, int W,
+                               void *arena, size_t arena_bytes, float *fused, float *const side_out[4], void *stream,
                                void *aux_stream);
 /* d_fused / d_side_out: upstream gradients ([N,1,H,W] fp32; d_fused or all four d_side_out may be NULL).
- * Must follow a fosvos_vgg_forward on the same arena, frame and shape.
+ * Must follow a fosvos_vgg_forward on the same arena, frame and shape; runs on ctx's device.
  * aux_stream (a second hipStream_t of the same device, or NULL): when given, every weight-gradient kernel is
  * issued on it while the data-gradient chain stays on `stream`; the two are ordered by events (a layer's wgrad
  * waits for that layer's output gradient; `stream` waits for the last wgrad before the call's work is complete
- * in stream order), so the caller sees ordinary single-stream semantics on `stream`.  The events are the one
- * piece of persistent state the library keeps (25 timing-disabled hipEvents per device, created on first use). */
-int fosvos_vgg_backward(const fosvos_vgg_weights *w, const fosvos_vgg_grads *g, const float *frame, int N, int H, int W,
-                        void *arena, size_t arena_bytes, const float *d_fused, const float *const d_side_out[4],
-                        int device, void *stream, void *aux_stream);
-/* Make `stream` wait until gradient bucket `bucket` of the LAST fosvos_vgg_backward on this device (called with
+ * in stream order), so the caller sees ordinary single-stream semantics on `stream`.  The events are the context's:
+ * the library itself keeps no state between calls. */
+int fosvos_vgg_backward(fosvos_ctx *ctx, const fosvos_vgg_weights *w, const fosvos_vgg_grads *g, const float *frame, int N,
+                        int H, int W, void *arena, size_t arena_bytes, const float *d_fused,
+                        const float *const d_side_out[4], void *stream, void *aux_stream);
+/* Make `stream` wait until gradient bucket `bucket` of the LAST fosvos_vgg_backward ON THIS CONTEXT (called with
  * grads.bucket_events != 0) is complete in its buffers: 0 = conv5_1..conv5_3 (stages.4), 1 = conv4_1..conv4_3
  * (stages.3), 2 = conv3_1..conv3_3 (stages.2) - 97 % of the gradient bytes, each published as the pass finishes it - then
  * 3 = conv1_1..conv2_2, 4 = side_prep / score_dsn / fuse (3 and 4 complete together, at the end of the pass, on both of
  * its streams).  Nothing blocks on the host.  The reference has no collective; this is the hook the
  * RCCL gradient all-reduce of BASELINE.json's north_star overlaps the backward pass with. */
-int fosvos_vgg_grad_bucket_wait(int device, int bucket, void *stream);
+int fosvos_vgg_grad_bucket_wait(fosvos_ctx *ctx, int bucket, void *stream);
 
 #ifdef __cplusplus
 }

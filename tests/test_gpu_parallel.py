@@ -73,8 +73,14 @@ def test_online_dp_on_gpu_equals_single_process(tmp_path):
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r), "2", str(port), str(tmp_path)])
              for r in range(2)]
-    for p in procs:
-        assert p.wait(timeout=600) == 0
+    try:
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+    finally:  # a failed or hung rank must not leave its peer alive on the GPU (it would wait in the collective)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
     res = [torch.load(os.path.join(str(tmp_path), f"dp{r}.pt")) for r in range(2)]
     assert res[0]["iterations"] == res[1]["iterations"] == N_FRAMES // 2
     ref, sd, ret = _train(_frames(), False)

@@ -33,6 +33,34 @@ def test_library_exports_every_header_symbol():
     assert lib.fosvos_conv3x3_workspace_bytes(1, 30, 54, 512, 512) > 0       # stage 5: split-K slabs
     assert lib.fosvos_head_bwd_workspace_bytes(1, 480, 854) > 0
     assert lib.fosvos_cbce_workspace_bytes(480 * 854) > 0
+    assert lib.fosvos_ctx_device(None) == -1
+
+
+def _plan(n, h, w, ci, co):
+    import ctypes
+    import fosvos_hip
+    info = fosvos_hip.Conv3x3PlanInfo()
+    fosvos_hip.check(fosvos_hip.lib().fosvos_conv3x3_plan(n, h, w, ci, co, ctypes.byref(info)), "conv3x3_plan")
+    return (info.tile_h, info.tile_w, info.tile_co, info.k_splits, info.workgroups)
+
+
+def test_conv_plan_of_the_480p_step():
+    """Which igemm instantiation each layer of the 854x480 step gets (host arithmetic of fosvos_conv3x3_plan): the GPU op
+    tests assert the same query for their cases, so this table is what ties them to the benchmarked configuration."""
+    # (N, H, W, Ci, Co) -> tile: stages 1-3 of one frame and every stage-1-4 layer of a five-frame pass run 256-pixel tiles
+    assert _plan(1, 480, 854, 64, 64)[:4] == (8, 32, 64, 1)
+    assert _plan(1, 240, 427, 64, 128)[:4] == (16, 16, 64, 1)
+    assert _plan(1, 240, 427, 128, 128)[:4] == (16, 16, 64, 1)
+    assert _plan(5, 120, 214, 128, 256)[:4] == (8, 32, 64, 1)
+    assert _plan(5, 60, 107, 512, 512)[:4] == (16, 16, 64, 1)
+    assert _plan(1, 120, 214, 64, 64)[:3] == (8, 16, 64)           # 105 blocks of 256 px: the 128-pixel tile
+    assert _plan(1, 30, 54, 512, 512)[3] > 1                       # stage 5 of one frame: split-K
+    assert _plan(1, 240, 427, 128, 16)[:3] == (8, 32, 16)          # side_prep at large maps
+    import ctypes
+    import fosvos_hip
+    tiles, wgs = ctypes.c_int(), ctypes.c_int()
+    fosvos_hip.check(fosvos_hip.lib().fosvos_conv3x3_first_plan(1, 480, 854, ctypes.byref(tiles), ctypes.byref(wgs)), "plan")
+    assert (tiles.value, wgs.value) == (60 * 27, 1024)             # the persistent conv1_1 loop iterates at 480x854
 
 
 def test_module_surface_matches_reference_contract():
@@ -55,6 +83,15 @@ def test_module_surface_matches_reference_contract():
     # whole-module pickles keep working and carry no device caches
     import pickle
     clone = pickle.loads(pickle.dumps(net))
+    assert list(clone.state_dict().keys()) == list(spec.keys())
+    # ... also after a training loop attached its flat gradient buffer (and possibly pending collectives) to the module
+    import parallel
+    named = list(net.named_parameters())
+    flat = parallel.FlatGrads.attach(net, [p for _, p in named], names=[n for n, _ in named])
+    flat._works.append(object())
+    assert net._fosvos_flat_grads is flat
+    clone = pickle.loads(pickle.dumps(net))
+    assert not hasattr(clone, "_fosvos_flat_grads") and all(p.grad is None for p in clone.parameters())
     assert list(clone.state_dict().keys()) == list(spec.keys())
 
 

@@ -135,8 +135,14 @@ def _launch(mode, tmp_path, world=2):
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r), str(world), str(port), mode, str(tmp_path)])
              for r in range(world)]
-    for p in procs:
-        assert p.wait(timeout=300) == 0
+    try:
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+    finally:  # a failed rank must not leave its peer waiting in a collective
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
     return [torch.load(os.path.join(str(tmp_path), f"{mode}{r}.pt")) for r in range(world)]
 
 
@@ -187,6 +193,54 @@ def test_flat_grad_buckets_of_the_real_module():
     assert 0 <= covered - (15267157 - frozen) <= pad
     spans = sorted(flat.slices)
     assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_flat_grad_bucket_ids_with_a_frozen_stage():
+    """A slice of the flat buffer keeps the NATIVE bucket id of its gradients (what fosvos_vgg_grad_bucket_wait takes): with
+    stage 4 frozen, slice 0 is bucket 1, and a tensor outside every bucket waits for the pass's last bucket."""
+    import parallel
+    from networks.osvos_vgg import OSVOS_VGG
+    net = OSVOS_VGG(pretrained=0)
+    for p in net.stages[4].parameters():
+        p.requires_grad_(False)
+    named = list(net.named_parameters())
+    flat = parallel.FlatGrads([p for _, p in named], names=[n for n, _ in named])
+    assert flat.bucket_ids == [1, 2, 3, 4] and len(flat.slices) == 4
+    seen = []
+    flat2 = parallel.FlatGrads([p for _, p in named], names=[n for n, _ in named],
+                               buckets=(("stages.3.",), ("stages.2.",)))  # everything else: trailing slices
+    assert flat2.bucket_ids[:2] == [0, 1] and set(flat2.bucket_ids[2:]) == {1} and len(flat2.slices) >= 3
+    full = parallel.FlatGrads([p for _, p in list(OSVOS_VGG(pretrained=0).named_parameters())])
+    assert full.bucket_ids == [len(parallel.VGG_BUCKETS) - 1]
+    del seen
+
+
+def test_offline_loop_tells_the_sampler_the_epoch():
+    """Data-parallel offline training draws a NEW shuffled order every epoch, like the reference's shuffle=True loader
+    (src/util/io_helper.py:62-70): `_train` calls sampler.set_epoch(epoch), without which a DistributedSampler replays the
+    same permutation."""
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    import train_offline
+    frames = _frames(8)
+    order = []
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(frames)
+
+        def __getitem__(self, i):
+            order.append(i)
+            return {k: v[0] for k, v in frames[i].items()}
+
+    sampler = DistributedSampler(DS(), num_replicas=2, rank=0, shuffle=True, seed=0)
+    loader = DataLoader(DS(), batch_size=1, sampler=sampler, num_workers=0)
+    train_offline.class_balanced_cross_entropy_loss = _cbce
+    train_offline.data_parallel = False
+    net = TinyOSVOS()
+    train_offline._train(_Prov(net), loader, None, _sgd(net), _Writer(), 0, 3, 2, 10 ** 9, False, 5)
+    epochs = [order[i:i + 4] for i in range(0, 12, 4)]
+    assert len(order) == 12 and len({tuple(e) for e in epochs}) > 1, epochs
 
 
 if __name__ == "__main__":
