@@ -40,7 +40,8 @@ def _ru(a: int, b: int) -> int:
 
 
 class Workspace:
-    """Grow-only scratch buffer per device (the library never allocates)."""
+    """Grow-only scratch buffer per device AND stream (the library never allocates): ops on one stream are ordered and may
+    share their scratch, two models driven on two streams (two host threads) must not."""
 
     def __init__(self) -> None:
         self._buf = {}
@@ -48,7 +49,8 @@ class Workspace:
     def get(self, nbytes: int, device: torch.device) -> Tuple[Optional[int], int]:
         if nbytes <= 0:
             return None, 0
-        key = device.index if device.index is not None else torch.cuda.current_device()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        key = (idx, torch.cuda.current_stream(idx).cuda_stream)
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(_ru(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -219,6 +221,24 @@ def conv3x3_first_wgrad(frame: torch.Tensor, dy: torch.Tensor) -> Tuple[torch.Te
                                        dev, st), "conv3x3_first_wgrad")
     _pe(t0, "conv1_1_wgrad", 2.0 * n * h * wd * 27 * co, n * h * wd * (12 + 2 * co))
     return dw, db
+
+
+def conv3x3_plan(n: int, h: int, w: int, in_ch: int, out_ch: int) -> dict:
+    """The igemm instantiation fosvos_conv3x3_fwd / _fwd_pool / _dgrad launch for this shape (host arithmetic only):
+    {"tile": (tile_h, tile_w, tile_co), "k_splits", "workgroups"}."""
+    import ctypes
+    from . import Conv3x3PlanInfo
+    info = Conv3x3PlanInfo()
+    check(lib().fosvos_conv3x3_plan(n, h, w, in_ch, out_ch, ctypes.byref(info)), "conv3x3_plan")
+    return {"tile": (info.tile_h, info.tile_w, info.tile_co), "k_splits": info.k_splits, "workgroups": info.workgroups}
+
+
+def conv3x3_first_plan(n: int, h: int, w: int) -> Tuple[int, int]:
+    """(tiles, persistent workgroups) of fosvos_conv3x3_first_fwd."""
+    import ctypes
+    tiles, wgs = ctypes.c_int(), ctypes.c_int()
+    check(lib().fosvos_conv3x3_first_plan(n, h, w, ctypes.byref(tiles), ctypes.byref(wgs)), "conv3x3_first_plan")
+    return tiles.value, wgs.value
 
 
 def conv3x3_fwd(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], ci: int, co: int,

@@ -391,3 +391,24 @@ def synthetic_frame(n: int, h: int, w: int, seed: int = 1234) -> Tuple[torch.Ten
     img = gt * (150.0 + 100.0 * noise) + (1.0 - gt) * (150.0 * noise)
     img = img - torch.tensor(BGR_MEAN, dtype=torch.float32).view(1, 3, 1, 1)
     return img, gt
+
+
+# ----------------------------------------------------------------------------------------------
+# Fine-tune trajectory fixture (tests/golden/trajectory.npz, written by oracle/make_golden.py section 6 with the
+# reference's own modules): the schedule and its inputs, seeds only, so every box rebuilds the same tensors
+# ----------------------------------------------------------------------------------------------
+TRAJ = {"seed": 41, "head_scale": 0.02, "lr": 1e-7, "iters": 60, "avg": 5, "h": 96, "w": 160, "frame_seed": 301,
+        "heldout_seed": 302}
+
+
+def trajectory_inputs():
+    """(parent state_dict, training frames [(x, gt)], held-out (x, gt)).  The parent is the seeded Kaiming net with its
+    fuse weights scaled down (logits start O(1), so the run is smooth); the training frames are the annotated frame and
+    its horizontal flip (src/dataloaders/custom_transforms.py:95-106 with the draw fixed); the held-out frame shows the
+    object displaced."""
+    sd = make_state_dict(TRAJ["seed"])
+    sd["fuse.weight"] = sd["fuse.weight"] * TRAJ["head_scale"]
+    x, gt = synthetic_frame(1, TRAJ["h"], TRAJ["w"], seed=TRAJ["frame_seed"])
+    frames = [(x, gt), (x.flip(3).contiguous(), gt.flip(3).contiguous())]
+    xh, gh = synthetic_frame(2, TRAJ["h"], TRAJ["w"], seed=TRAJ["heldout_seed"])
+    return sd, frames, (xh[1:].contiguous(), gh[1:].contiguous())

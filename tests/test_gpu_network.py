@@ -31,6 +31,13 @@ GRAD_REL_L2 = 0.15
 # than the fp32 comparison; measured worst case cos 0.9981 / rel 6.2e-2.
 GRAD_COS_EMU = 0.995
 GRAD_REL_L2_EMU = 0.10
+# The 60-iteration fine-tune trajectory against the reference's (tests/golden/trajectory.npz): twelve optimizer steps, each
+# fed by gradients that carry the bf16 forward noise above, from weights that already differ a little - stated separately
+# from the single-step tolerances and measured on MI355X.
+TRAJ_IOU_TOL = 1e-3        # north_star: per-pixel mask IoU within 1e-3 of the reference
+TRAJ_LOGIT_TOL = 5e-2      # held-out logits after training, share of the logit range
+TRAJ_LOSS_RTOL = 5e-2
+TRAJ_DELTA_REL_L2 = 0.25
 
 
 def make_net(seed, scheme="kaiming"):
@@ -199,42 +206,48 @@ class _OneShotLoader:
         return iter(self._batches)
 
 
-def _check_deltas(net, sd, k, prefix, frozen):
-    """Applied weight deltas of EVERY tensor the reference's trace holds (64 strided samples each) against ours."""
+def _check_deltas(net, sd, k, prefix, frozen, full_key="fulldelta", dense_key="dense", tol=GRAD_REL_L2):
+    """Applied weight deltas of EVERY tensor against the reference's: tensors of at most 64 k elements element by element
+    (the fixture holds them whole), the larger ones on 4096 strided samples.  Per tensor: relative L2 error within the
+    stated gradient tolerance (rel-L2 <= 0.15 vs the fp32 reference on random weights) - no allowance
+    on top, the estimate no longer rests on 64 samples - and the sum of |delta| over ALL elements within the same share."""
     worst = ("", 0.0)
     ratios = []
     for name, p in net.named_parameters():
         got_all = p.detach().cpu().double().reshape(-1) - sd[name].double().reshape(-1)
-        idx = torch.from_numpy(k[f"{prefix}_delta_{name}_i"])
-        ref = torch.from_numpy(k[f"{prefix}_delta_{name}_s"]).double()
+        if f"{prefix}_{full_key}_{name}" in k.files:
+            ref = torch.from_numpy(k[f"{prefix}_{full_key}_{name}"]).double().reshape(-1)
+            got = got_all
+        else:
+            idx = torch.from_numpy(k[f"{prefix}_{dense_key}_{name}_i"])
+            ref = torch.from_numpy(k[f"{prefix}_{dense_key}_{name}_s"]).double()
+            got = got_all[idx]
         if name.startswith(frozen):
             assert float(ref.abs().max()) == 0.0 and torch.equal(p.detach().cpu(), sd[name]), name
             continue
         scale = ref.abs().max().item()
         # fp32 masters: an update of lr * grad sits near the fp32 resolution of the weight itself
         ulp = float(np.spacing(np.float32(max(sd[name].abs().max().item(), 1e-30))))
-        d = got_all[idx] - ref
+        d = got - ref
         if scale == 0:  # the reference's update was below the fp32 resolution of the weight: ours may be one step at most
             assert d.abs().max().item() <= 2 * ulp, name
             continue
-        # the stated gradient tolerance (DESIGN.md section 4: rel-L2 <= 0.15 vs the fp32 reference on random weights) over
-        # the tensor's samples, with no single element off by more than twice that share of the largest delta
         noise = 2 * ulp * float(np.sqrt(d.numel()))
         ratio = max(d.norm().item() - noise, 0.0) / ref.norm().item()
         if ratio > worst[1]:
             worst = (name, ratio)
         ratios.append(ratio)
-        # 64 strided samples estimate a tensor's rel-L2 only to a few tens of percent (the bf16 error field is heavy-tailed):
-        # a single tensor may read up to 1.5x the stated tolerance, the RMS over all tensors (below) may not exceed it
-        assert ratio <= 1.5 * GRAD_REL_L2, (name, ratio)
-        assert d.abs().max().item() <= 2 * GRAD_REL_L2 * scale + 2 * ulp, (name, d.abs().max().item(), scale, ulp)
-        # moments of the whole delta tensor (sum |d|): direction-free size check of ALL elements, not the samples
-        m_ref = float(k[f"{prefix}_delta_{name}_m"][1])
-        m_got = float(got_all.abs().sum())
-        n_el = got_all.numel()
-        assert abs(m_got - m_ref) <= GRAD_REL_L2 * m_ref + 2 * ulp * n_el, (name, m_got, m_ref)
+        assert ratio <= tol, (name, ratio)
+        # moments of the whole delta tensor (sum |d|): direction-free size check of ALL elements
+        if f"{prefix}_delta_{name}_m" in k.files:
+            m_ref = float(k[f"{prefix}_delta_{name}_m"][1])
+        else:
+            m_ref = float(ref.abs().sum()) if got is got_all else None
+        if m_ref is not None:
+            m_got = float(got_all.abs().sum())
+            assert abs(m_got - m_ref) <= tol * m_ref + 2 * ulp * got_all.numel(), (name, m_got, m_ref)
     rms = float(np.sqrt(np.mean(np.square(ratios))))
-    assert rms <= GRAD_REL_L2, f"RMS over {len(ratios)} tensors of the sampled delta rel-L2: {rms:.3f}"
+    print(f"[{prefix}] delta rel-L2: worst {worst[1]:.3e} at {worst[0]}, RMS over {len(ratios)} tensors {rms:.3e}")
     return worst
 
 
@@ -266,6 +279,76 @@ def test_shipped_online_train_vs_golden(golden, tag, lr):
     assert net.compute_side_outputs is True and net.defer_wgrad_join is False
     outs = net(frames[0][0].to(DEV))
     assert all(tuple(o.shape) == (1, 1, 48, 86) for o in outs)
+
+
+def test_finetune_trajectory_vs_reference(golden):
+    """BASELINE's "mask IoU vs ref" AFTER fine-tuning: `train_online._train` (the shipped loop: grouped passes, split
+    optimizer step, bf16 activations) on the schedule the REFERENCE ran for tests/golden/trajectory.npz - 60 iterations,
+    step every 5, the annotated frame and its flip (src/train_online.py:23-50,70-107) - then the held-out frame through the
+    fine-tuned weights.  Compared: every iteration's loss, the held-out MASK of HIP-fine-tuned weights against the mask of
+    reference-fine-tuned weights, the logits, and the applied delta of every tensor."""
+    import train_online
+    from util.network_provider import VGGOnlineProvider
+    k = golden("trajectory.npz")
+    T = O.TRAJ
+    sd, frames, (xh, gh) = O.trajectory_inputs()
+    from networks.osvos_vgg import OSVOS_VGG
+    net = OSVOS_VGG(pretrained=0)
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    prov = VGGOnlineProvider.__new__(VGGOnlineProvider)
+    prov.network = net
+    prov.name = "vgg16"
+    opt = prov.get_optimizer(learning_rate=T["lr"])
+    loader = [{"image": x, "gt": gt} for x, gt in frames]
+    train_online.data_parallel = False
+    n_epochs = T["iters"] // len(loader)
+    ret = train_online._train(prov, loader, opt, _NullWriter(), "trajectory", 0, n_epochs, T["avg"], 10 ** 9)
+    assert ret["iterations"] == T["iters"]
+    # the loop logs running_loss / len(loader) at 20 points: with 30 epochs, the sum of each epoch's losses... every 1.5
+    # epochs; compare what it holds: sums over the iterations between two logging points
+    log_every = max(n_epochs // 20, 1)
+    ref_loss = np.array(k["loss"]).reshape(n_epochs, len(loader)).sum(axis=1)
+    ref_logged = [ref_loss[e - log_every + 1: e + 1].sum() / len(loader) for e in range(n_epochs) if e % log_every == log_every - 1]
+    got_logged = np.array(ret["loss"])
+    assert len(got_logged) == len(ref_logged)
+    rel = np.abs(got_logged - ref_logged) / np.array(ref_logged)
+    print(f"[trajectory] logged losses: max rel deviation {rel.max():.3e} (first {rel[0]:.2e}, last {rel[-1]:.2e})")
+    with torch.no_grad():
+        held = net(xh.to(DEV))[-1][0, 0].cpu()
+    ref = torch.from_numpy(k["heldout_logits"])
+    ref_mask = ref >= 0
+    gt_mask = gh[0, 0] > 0.5
+    iou = O.mask_iou(held >= 0, ref_mask)
+    iou_gt_hip, iou_gt_ref = O.mask_iou(held >= 0, gt_mask), O.mask_iou(ref_mask, gt_mask)
+    err = (held - ref).abs().max().item() / ref.abs().max().item()
+    flips = int(((held >= 0) != ref_mask).sum())
+    band = ref.abs() > LOGIT_TOL * ref.abs().max()
+    print(f"[trajectory] IoU(hip-finetuned, ref-finetuned)={iou:.5f} ({flips} of {ref.numel()} pixels differ, "
+          f"{int((~band).sum())} inside the logit band)  IoU vs gt: hip {iou_gt_hip:.4f} ref {iou_gt_ref:.4f}  "
+          f"logit err {err:.3e} of range")
+    worst = _check_deltas(net, sd, _TrajKeys(k), "traj", ("upscale", "score_dsn"), tol=TRAJ_DELTA_REL_L2)
+    np.testing.assert_allclose(got_logged, ref_logged, rtol=TRAJ_LOSS_RTOL)
+    assert iou_gt_ref > 0.8 and abs(iou_gt_hip - iou_gt_ref) <= TRAJ_IOU_TOL
+    assert abs(iou - 1.0) <= TRAJ_IOU_TOL, iou
+    assert torch.equal((held >= 0)[band], ref_mask[band])  # masks agree wherever the reference is not within the logit band of 0
+    assert err < TRAJ_LOGIT_TOL
+
+
+class _TrajKeys:
+    """trajectory.npz under the key names _check_deltas reads (full tensors: delta_<name>; digests: delta_<name>_{i,s,m})."""
+
+    def __init__(self, k):
+        self._k = k
+        self.files = []
+        for nm in k["full_tensors"]:
+            self.files.append(f"traj_fulldelta_{nm}")
+        for nm in k["digest_tensors"]:
+            self.files += [f"traj_dense_{nm}_i", f"traj_dense_{nm}_s", f"traj_delta_{nm}_m"]
+
+    def __getitem__(self, key):
+        _kind, name = key[len("traj_"):].split("_", 1)  # traj_<kind>_<name...> -> delta_<name...>
+        return self._k[f"delta_{name}"]
 
 
 def test_grouped_micro_batches_equal_one_by_one(monkeypatch):
@@ -498,6 +581,79 @@ def test_gradient_buckets_are_published_in_completion_order():
                     assert torch.equal(p.grad, plain[n_]), n_
         net2.defer_wgrad_join = False
         net2.last_pass_of_cycle = False
+
+
+def test_two_models_on_one_device_keep_their_own_events():
+    """The events that order a model's two-stream passes and publish its gradient buckets live in the model's own
+    fosvos_ctx (include/fosvos_hip.h), not in the library: two models driven from two host threads on one GPU, each on its
+    own pair of streams, with deferred joins and published buckets, end with exactly the gradients each computes alone;
+    and a bucket wait issued for model A after model B's backward pass still refers to A's pass."""
+    import threading
+    import parallel
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    frames = {"a": [O.synthetic_frame(1, 61, 107, seed=200 + i) for i in range(3)],
+              "b": [O.synthetic_frame(1, 48, 86, seed=210 + i) for i in range(3)]}
+    seeds = {"a": 31, "b": 32}
+
+    def run(tag, out, stream=None, barrier=None):
+        net, _ = make_net(seeds[tag])
+        named = list(net.named_parameters())
+        flat = parallel.FlatGrads([p for _, p in named], names=[n_ for n_, _ in named])
+        net.accumulate_grads_in_place = True
+        net.defer_wgrad_join = True
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            for rep in range(4):
+                for i, (x, gt) in enumerate(frames[tag]):
+                    if barrier is not None:
+                        barrier.wait()  # both threads issue their passes at the same time
+                    net.publish_grad_buckets = i == len(frames[tag]) - 1
+                    cbce(net(x.to(DEV))[-1], gt.to(DEV), size_average=False).backward()
+                for b in range(len(flat.slices)):
+                    net.wait_grad_bucket(flat.bucket_ids[b])
+                net.join_gradients()
+            torch.cuda.current_stream().synchronize()
+        net.defer_wgrad_join = False
+        out[tag] = flat.flat.clone()
+
+    alone, together = {}, {}
+    run("a", alone)
+    run("b", alone)
+    bar = threading.Barrier(2)
+    threads = [threading.Thread(target=run, args=(t, together, torch.cuda.Stream(), bar)) for t in ("a", "b")]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert set(together) == {"a", "b"}, "a worker thread died"
+    for t in ("a", "b"):
+        assert torch.equal(alone[t], together[t]), t
+
+    # one thread, alternating: A's bucket wait after B's backward pass waits for A's events
+    net_a, _ = make_net(31)
+    net_b, _ = make_net(32)
+    for net in (net_a, net_b):
+        net.accumulate_grads_in_place = True
+        net.defer_wgrad_join = True
+        net.publish_grad_buckets = True
+    (xa, ga), (xb, gb) = frames["a"][0], frames["b"][0]
+    cbce(net_a(xa.to(DEV))[-1], ga.to(DEV), size_average=False).backward()
+    net_b.publish_grad_buckets = False
+    cbce(net_b(xb.to(DEV))[-1], gb.to(DEV), size_average=False).backward()   # B published nothing ...
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        net_a.wait_grad_bucket(0, side)                                          # ... A's buckets are still there
+        snap = net_a.stages[4][5].weight.grad.clone()
+    from fosvos_hip import FosvosHipError
+    with pytest.raises(FosvosHipError):
+        net_b.wait_grad_bucket(0)
+    side.synchronize()
+    for net in (net_a, net_b):
+        net.join_gradients()
+        net.defer_wgrad_join = False
+    torch.cuda.synchronize()
+    assert torch.equal(snap, net_a.stages[4][5].weight.grad)
 
 
 def test_inplace_grad_accumulation_matches_autograd():

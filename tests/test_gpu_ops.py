@@ -146,7 +146,7 @@ CONV_CASES = [
     (1, 15, 27, 256, 128),   # TileSmall, 8 K chunks
     (1, 7, 5, 64, 64),       # smaller than one tile
     (1, 1, 1, 64, 64),       # degenerate
-    (1, 120, 214, 64, 64),   # TileBig with >512 blocks
+    (1, 120, 214, 64, 64),   # 105 workgroups of 256 px: still the 128-pixel tile (the 256-px tiles: HOT_CASES below)
 ]
 
 
@@ -283,6 +283,143 @@ def test_conv3x3_wgrad(ops, n, h, w, ci, co):
     dw4, db4 = ops.conv3x3_wgrad_one_call(to_nhwc_bf16(x), dy_dev, ci, co)
     assert torch.equal(dw4, dw) and torch.equal(db4, db)
     assert torch.equal(dw3, dw)
+
+
+# ------------------------------------------------------------------------------------------ the instantiations the 480x854 step runs
+# The 256-pixel tiles (8x32 and 16x16 x 64 channels) are only selected when a launch has >= 256 of them: these are the kernels
+# behind 47 % of the fine-tune step's time (five frames per launch).  Each case states the tile fosvos_conv3x3_plan must
+# report, so a later change of the selection rule cannot silently move these tests onto other kernels.
+HOT_CASES = [
+    # n, h, w, ci, co, tile
+    (1, 240, 427, 64, 128, (16, 16, 64)),   # conv2_1 of one frame: 16x16 tiles, ragged right edge (427 = 26 * 16 + 11)
+    (5, 120, 214, 128, 128, (8, 32, 64)),   # five frames per launch, stage-3 map: 8x32 tiles, 214 = 6 * 32 + 22
+    (1, 480, 854, 64, 64, (8, 32, 64)),     # conv1_2 at full size: 1620 workgroups, XCD-swizzled 1-D grid
+    (5, 60, 107, 128, 128, (16, 16, 64)),   # five frames, stage-4 map: 16x16 tiles overhang 60x107 less than 8x32 ones
+]
+
+
+def _assert_tile(ops, n, h, w, in_ch, out_ch, tile):
+    plan = ops.conv3x3_plan(n, h, w, in_ch, out_ch)
+    assert plan["tile"] == tile and plan["k_splits"] == 1, f"{(n, h, w, in_ch, out_ch)} runs {plan}, the test is about {tile}"
+    assert plan["workgroups"] >= 256
+
+
+@pytest.mark.parametrize("n,h,w,ci,co,tile", HOT_CASES)
+def test_conv3x3_fwd_hot_tiles(ops, n, h, w, ci, co, tile):
+    """Forward conv + bias + ReLU on the 256-pixel tiles, whole tensors against torch fp32 on identically rounded inputs;
+    the same launch with the fused ceil-mode pool: y bit-identical, pooled map exactly the pool of y."""
+    _assert_tile(ops, n, h, w, ci, co, tile)
+    x = bf(gen(n, ci, h, w, seed=110))
+    wt = gen(co, ci, 3, 3, seed=111, scale=math.sqrt(2.0 / (9 * ci)))
+    b = gen(co, seed=112, scale=0.2)
+    ref = F.relu(F.conv2d(x, bf(wt), b, padding=1))
+    wf, _ = ops.pack_conv3x3_weights(wt.to(DEV))
+    xd = to_nhwc_bf16(x)
+    y = ops.conv3x3_fwd(xd, wf, b.to(DEV), ci, co, relu=True)
+    assert_bf16_close(from_nhwc(y), ref, f"conv3x3_fwd {tile} {n}x{h}x{w} {ci}->{co}")
+    y2, yp = ops.conv3x3_fwd_pool(xd, wf, b.to(DEV), ci, co, relu=True)
+    assert torch.equal(y2, y)
+    assert torch.equal(from_nhwc(yp), F.max_pool2d(from_nhwc(y), 2, 2, ceil_mode=True))
+    # no ReLU: negative values through the pool's float path
+    y3, yp3 = ops.conv3x3_fwd_pool(xd, wf, b.to(DEV), ci, co, relu=False)
+    assert_bf16_close(from_nhwc(y3), F.conv2d(x, bf(wt), b, padding=1), "conv3x3_fwd_pool linear")
+    assert torch.equal(from_nhwc(yp3), F.max_pool2d(from_nhwc(y3), 2, 2, ceil_mode=True))
+
+
+@pytest.mark.parametrize("n,h,w,ci,co,tile", HOT_CASES)
+def test_conv3x3_dgrad_hot_tiles(ops, n, h, w, ci, co, tile):
+    """Data gradient on the 256-pixel tiles (contraction over the forward op's outputs, so the plan is queried with the
+    channel roles swapped): plain, and with the ReLU mask of the producer + the other consumer's gradient added in place
+    (the epilogue that reads both through buffer descriptors)."""
+    # the tile of the dgrad launch: in = co, out = ci
+    plan = ops.conv3x3_plan(n, h, w, co, ci)
+    assert plan["tile"][:2] == tile[:2] and plan["tile"][2] == 64 and plan["k_splits"] == 1 and plan["workgroups"] >= 256, plan
+    dy = bf(gen(n, co, h, w, seed=120))
+    wt = gen(co, ci, 3, 3, seed=121, scale=math.sqrt(2.0 / (9 * ci)))
+    xin = torch.zeros(n, ci, h, w, requires_grad=True)
+    F.conv2d(xin, bf(wt), None, padding=1).backward(dy)
+    ref = xin.grad
+    _, wd = ops.pack_conv3x3_weights(wt.to(DEV))
+    dyd = to_nhwc_bf16(dy)
+    dx = ops.conv3x3_dgrad(dyd, wd, ci, co)
+    assert_bf16_close(from_nhwc(dx), ref, f"conv3x3_dgrad {tile}")
+    act = bf(F.relu(gen(n, ci, h, w, seed=122)))
+    add = bf(gen(n, ci, h, w, seed=123))
+    ref2 = bf(bf(ref) * (act > 0).float() + add)
+    add_dev = to_nhwc_bf16(add)
+    dx2 = ops.conv3x3_dgrad(dyd, wd, ci, co, relu_src=to_nhwc_bf16(act), addend=add_dev, out=add_dev)
+    assert dx2.data_ptr() == add_dev.data_ptr()
+    got = from_nhwc(dx2)
+    tol = (2.0 ** -7) * ref2.abs() + 1e-5 * ref2.abs().max() + (2.0 ** -7) * ref.abs()
+    assert ((got - ref2).abs() <= tol).all(), f"dgrad mask+add {tile}: rel err {rel_err(got, ref2):.3e}"
+    # mask only (what the dgrad of a conv inside a stage runs)
+    dx3 = ops.conv3x3_dgrad(dyd, wd, ci, co, relu_src=to_nhwc_bf16(act))
+    assert torch.equal(from_nhwc(dx3), from_nhwc(dx) * (act > 0).float())
+
+
+@pytest.mark.parametrize("n,h,w,ci,tile", [(1, 240, 427, 128, (16, 16, 64)), (5, 120, 214, 256, (8, 32, 64))])
+def test_conv3x3_dgrad_side_hot_tiles(ops, n, h, w, ci, tile):
+    """side_prep data gradient at the sizes of the step: 16 real channels zero-padded to one K chunk of 32, the stage
+    output's ReLU mask and the gradient that came back through the next stage's pool added in place."""
+    _assert_tile(ops, n, h, w, 16, ci, tile)
+    dy = bf(gen(n, 16, h, w, seed=124))
+    wt = gen(16, ci, 3, 3, seed=125, scale=0.05)
+    xin = torch.zeros(n, ci, h, w, requires_grad=True)
+    F.conv2d(xin, bf(wt), None, padding=1).backward(dy)
+    ref = xin.grad
+    _, wd = ops.pack_conv3x3_weights(wt.to(DEV))
+    dy_pad = torch.zeros(n, h, w, 32, dtype=torch.bfloat16, device=DEV)
+    dy_pad[..., :16] = to_nhwc_bf16(dy)
+    act = bf(F.relu(gen(n, ci, h, w, seed=126)))
+    add = bf(gen(n, ci, h, w, seed=127))
+    add_dev = to_nhwc_bf16(add)
+    dx = ops.conv3x3_dgrad(dy_pad, wd, ci, 16, relu_src=to_nhwc_bf16(act), addend=add_dev, out=add_dev)
+    ref2 = bf(bf(ref) * (act > 0).float() + add)
+    got = from_nhwc(dx)
+    tol = (2.0 ** -7) * ref2.abs() + 1e-5 * ref2.abs().max() + (2.0 ** -7) * ref.abs()
+    assert ((got - ref2).abs() <= tol).all(), f"side dgrad {tile}: rel err {rel_err(got, ref2):.3e}"
+
+
+def test_conv3x3_side_prep_fwd_large_map(ops):
+    """side_prep forward at a five-frame stage-2 map: the 256-pixel x 16-channel tile, fp32 output."""
+    n, h, w, ci = 5, 240, 427, 128
+    assert ops.conv3x3_plan(n, h, w, ci, 16)["tile"] == (8, 32, 16)
+    x = bf(gen(n, ci, h, w, seed=128))
+    wt = gen(16, ci, 3, 3, seed=129, scale=math.sqrt(1.0 / (9 * ci)))
+    b = gen(16, seed=130, scale=0.2)
+    wf, _ = ops.pack_conv3x3_weights(wt.to(DEV))
+    y = ops.conv3x3_fwd(to_nhwc_bf16(x), wf, b.to(DEV), ci, 16, relu=False, out_f32=True)
+    assert rel_err(from_nhwc(y), F.conv2d(x, bf(wt), b, padding=1)) < 2e-5
+
+
+def test_conv_first_fwd_persistent_loop(ops):
+    """conv1_1 at 1x480x854: 1620 tiles on 1024 persistent workgroups, so the tile loop and its double-buffered staging
+    iterate (every smaller case above runs one tile per workgroup)."""
+    n, h, w = 1, 480, 854
+    tiles, wgs = ops.conv3x3_first_plan(n, h, w)
+    assert tiles > wgs == 1024
+    x = gen(n, 3, h, w, seed=131, scale=60.0)
+    wt = gen(64, 3, 3, 3, seed=132, scale=0.2)
+    b = gen(64, seed=133, scale=0.5)
+    y = ops.conv3x3_first_fwd(x.to(DEV), wt.to(DEV), b.to(DEV))
+    assert_bf16_close(from_nhwc(y), F.relu(F.conv2d(x, wt, b, padding=1)), "conv_first_fwd 480x854")
+
+
+def test_conv3x3_wgrad_five_frames(ops):
+    """Weight gradient of a five-frame launch at a stage-3 map (what the step runs: 192 pixel splits, tiles of several
+    images per split), against torch fp32 on the same bf16 operands; bit-reproducible."""
+    n, h, w, ci, co = 5, 120, 214, 128, 256
+    x = bf(gen(n, ci, h, w, seed=134))
+    dy = bf(gen(n, co, h, w, seed=135))
+    wt = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    b = torch.zeros(co, requires_grad=True)
+    F.conv2d(x, wt, b, padding=1).backward(dy)
+    xd, dyd = to_nhwc_bf16(x), to_nhwc_bf16(dy)
+    dw, db = ops.conv3x3_wgrad(xd, dyd, ci, co)
+    assert rel_err(dw.cpu(), wt.grad) < 5e-5, f"wgrad rel err {rel_err(dw.cpu(), wt.grad):.3e}"
+    assert rel_err(db.cpu(), b.grad) < 5e-5
+    dw2, db2 = ops.conv3x3_wgrad(xd, dyd, ci, co)
+    assert torch.equal(dw2, dw) and torch.equal(db2, db)
 
 
 # ------------------------------------------------------------------------------------------ pool

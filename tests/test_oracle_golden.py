@@ -187,6 +187,51 @@ def test_online_loop(golden, tag, lr):
             assert torch.equal(final[nm], sd[nm])
 
 
+def test_finetune_trajectory(golden):
+    """The oracle's online loop follows the REFERENCE's 60-iteration fine-tune (oracle/make_golden.py section 6): losses,
+    the held-out logits and mask after training, and the full applied delta of every small tensor."""
+    k = golden("trajectory.npz")
+    for key, val in O.TRAJ.items():
+        assert float(k[key]) == float(val), key
+    sd, frames, (xh, gh) = O.trajectory_inputs()
+    losses, final = O.online_loop(sd, [f[0] for f in frames], [f[1] for f in frames], O.TRAJ["iters"], O.TRAJ["avg"],
+                                  lr=O.TRAJ["lr"])
+    np.testing.assert_allclose(losses, k["loss"], rtol=1e-3)
+    assert k["loss"][-1] < 0.1 * k["loss"][0]  # the schedule does train
+    with torch.no_grad():
+        held = O.forward(final, xh)[-1][0, 0]
+    ref = torch.from_numpy(k["heldout_logits"])
+    assert (held - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()
+    ref_mask = torch.from_numpy(np.unpackbits(k["heldout_mask_bits"])[: ref.numel()].reshape(ref.shape)).bool()
+    assert torch.equal(ref_mask, ref >= 0)
+    gt_mask = torch.from_numpy(np.unpackbits(k["heldout_gt_bits"])[: ref.numel()].reshape(ref.shape)).bool()
+    assert torch.equal(gt_mask, gh[0, 0] > 0.5)
+    assert abs(O.mask_iou(held >= 0, ref_mask) - 1.0) <= 1e-3
+    start = torch.from_numpy(k["heldout_logits_start"])
+    assert O.mask_iou(start >= 0, gt_mask) < 0.05 < 0.8 < O.mask_iou(ref_mask, gt_mask)  # the mask moved onto the object
+    for nm in k["full_tensors"]:
+        nm = str(nm)
+        d = (final[nm].double() - sd[nm].double()).numpy()
+        ref_d = k[f"delta_{nm}"]
+        scale = np.abs(ref_d).max()
+        if nm.startswith(("upscale", "score_dsn")):
+            assert scale == 0 and np.abs(d).max() == 0
+            continue
+        ulp = float(np.spacing(np.float32(sd[nm].abs().max().item())))
+        # 60 iterations of fp32 arithmetic in two statements of the same graph (nn modules vs functional calls): the
+        # summation orders of the threaded CPU kernels differ, and twelve optimizer steps carry that forward
+        assert np.abs(d - ref_d).max() <= 1e-2 * scale + 2 * ulp, nm
+        assert np.linalg.norm(d - ref_d) <= 5e-3 * np.linalg.norm(ref_d) + 2 * ulp * np.sqrt(d.size), nm
+    for nm in k["digest_tensors"]:
+        nm = str(nm)
+        d = final[nm].double() - sd[nm].double()
+        ulp = float(np.spacing(np.float32(sd[nm].abs().max().item())))
+        smp = k[f"delta_{nm}_s"]
+        got = d.reshape(-1)[torch.from_numpy(k[f"delta_{nm}_i"])].numpy()
+        assert np.abs(got - smp).max() <= 1e-2 * np.abs(smp).max() + 2 * ulp, nm
+        assert np.linalg.norm(got - smp) <= 5e-3 * np.linalg.norm(smp) + 2 * ulp * np.sqrt(got.size), nm
+
+
 def test_offline_loop(golden):
     k = golden("loops.npz")
     sd = O.make_state_dict(8)
