@@ -82,6 +82,17 @@ def _max_group() -> int:
         return 5
 
 
+def _group_window() -> int:
+    """How many micro-batches of an accumulation cycle the loop looks at together before it forms its batched passes
+    (FOSVOS_GROUP_WINDOW, default 16; never more than the cycle itself).  The reference's augmentation draws a random scale
+    per iteration (src/dataloaders/custom_transforms.py:63-76), so consecutive frames rarely share a size; gradients inside a
+    cycle are a sum, so the micro-batches of the window are bucketed BY SHAPE and every bucket runs as one batched pass."""
+    try:
+        return max(1, int(os.environ.get('FOSVOS_GROUP_WINDOW', '16')))
+    except ValueError:
+        return 16
+
+
 def _losses_per_frame(fused, gts):
     """[k] per-frame losses of a batched pass; one fused op on the GPU, the reference's function per slice elsewhere."""
     if fused.is_cuda and class_balanced_cross_entropy_loss is _hip_cbce:
@@ -145,7 +156,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     # syncs that drain the launch queue).  Here every pass sends its per-frame losses to pinned memory with ONE asynchronous
     # copy and the host does the bookkeeping (running sum, logging points) once the copy has landed: no device-side
     # accumulator kernels, no sync.  `loss_tr` fills in iteration order, a few passes behind the device.
-    pending_logs = []   # (frames [(epoch, minibatch index)], host tensor with their losses, event)
+    pending_logs = []   # per window: ([(epoch, minibatch index, host tensor, position)] in iteration order, event, ring slots)
     ring, ring_free = None, []
     if device.type == 'cuda':
         ring = torch.empty((64, max_group), dtype=torch.float32).pin_memory()
@@ -154,13 +165,13 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
 
     def flush_logs(block: bool) -> None:
         while pending_logs:
-            frames, host_vals, landed, slot = pending_logs[0]
+            items, landed, slots = pending_logs[0]
             if block:
                 landed.synchronize()
             elif not landed.query():
                 break
             pending_logs.pop(0)
-            for i, (ep, mb) in enumerate(frames):
+            for ep, mb, host_vals, i in items:  # iteration order of the reference's loop, whatever order the passes ran in
                 running_host[0] += float(host_vals[i])
                 if is_log_epoch(ep):
                     value = running_host[0] / n_samples
@@ -169,15 +180,19 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
                     log.info('[Epoch {0}: {1}, numImages: {2}]'.format(seq_name, ep + 1, mb + 1))
                     log.info('Loss {0}: {1}'.format(seq_name, value))
                     summary_writer.add_scalar('data/total_loss_epoch', value, ep)
-            if slot is not None:
-                ring_free.append(slot)
+            ring_free.extend(slots)
+
+    window_logs = []  # (frames, host tensor, event, ring slot) of the passes of the window being run
 
     def record_losses(group, losses) -> None:
-        """losses: [k] detached device tensor, frame by frame in loop order."""
+        """losses: [k] detached device tensor, frame by frame in the order of `group`."""
         frames = [(g[0], g[1]) for g in group]
         if ring is not None:
             if not ring_free:
                 flush_logs(True)
+            if not ring_free:  # every slot is held by the window in flight: a plain (pageable, synchronous) copy instead
+                window_logs.append((frames, losses.to('cpu'), _Landed(), None))
+                return
             slot = ring_free.pop()
             host_vals = ring[slot, :len(frames)]
             host_vals.copy_(losses, non_blocking=True)
@@ -185,7 +200,18 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             landed.record()
         else:  # CPU tensors (the gloo tests of the data-parallel wiring): nothing to wait for
             slot, host_vals, landed = None, losses.clone(), _Landed()
-        pending_logs.append((frames, host_vals, landed, slot))
+        window_logs.append((frames, host_vals, landed, slot))
+
+    def close_window_logs() -> None:
+        """The passes of a window ran bucket by bucket; the bookkeeping (running loss, logging points) follows the
+        reference's iteration order: one pending entry per window, sorted, waiting on the window's last copy."""
+        if not window_logs:
+            return
+        items = sorted(((ep, mb, host_vals, i) for frames, host_vals, _, _ in window_logs
+                        for i, (ep, mb) in enumerate(frames)), key=lambda t: (t[0], t[1]))
+        slots = [slot for _, _, _, slot in window_logs if slot is not None]
+        pending_logs.append((items, window_logs[-1][2], slots))
+        window_logs.clear()
         flush_logs(False)
 
     def is_log_epoch(epoch: int) -> bool:
@@ -195,8 +221,8 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         return (epoch % snapshot_every_n) == snapshot_every_n - 1
 
     def run_group(group) -> None:
-        """One forward / loss / backward pass over the micro-batches of `group` (consecutive iterations of the reference's
-        loop, same frame size, inside one accumulation cycle).  The weights do not change inside a cycle, so running k
+        """One forward / loss / backward pass over the micro-batches of `group` (iterations of the reference's loop with
+        the same frame size, inside one accumulation cycle; consecutive or not - see run_window).  The weights do not change inside a cycle, so running k
         iterations as one batch of k frames leaves every frame's logits, loss (the class weights are still counted per
         frame) and gradient contribution what the one-by-one loop computes; only the order of the fp32 sums over frames
         differs.  What it buys on the GPU: k frames per kernel launch (the small stage-5 layers fill the chip without
@@ -267,31 +293,42 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
                 flat.zero()
             counter_gradient = 0
 
-        epoch, _idx, _mb, end_of_epoch = group[-1]
+    def run_window(window) -> None:
+        """The micro-batches the loop has collected (all inside one accumulation cycle, in iteration order) as batched
+        passes: bucketed by frame shape in order of first appearance, each bucket cut into groups of at most `max_group`
+        frames.  The cycle's gradient is a sum over its micro-batches, so the order of the passes changes nothing but the
+        order of fp32 additions - and a loader that yields the same frames already sorted by shape runs the IDENTICAL
+        passes (tested bit for bit).  Minibatches that are batches themselves (N > 1) run alone."""
+        buckets = {}
+        for item in window:
+            shape = tuple(item[2]['image'].shape)
+            buckets.setdefault(shape if shape[0] == 1 else ('batch', id(item)), []).append(item)
+        groups = [items[i:i + max_group] for items in buckets.values() for i in range(0, len(items), max_group)]
+        for group in groups:
+            run_group(group)
+        close_window_logs()
+        epoch, _idx, _mb, end_of_epoch = window[-1]
         if end_of_epoch and is_snapshot_epoch(epoch) and parallel.rank() == 0:
             net_provider.save_model(epoch, sequence=seq_name)
 
     time_all_start = timeit.default_timer()
     n_iters = 0
     max_group = _max_group()
-    group = []  # pending (epoch, minibatch index, minibatch, last of its epoch) tuples
+    max_window = max(max_group, _group_window())
+    window = []  # pending (epoch, minibatch index, minibatch, last of its epoch) tuples, all of one accumulation cycle
     for epoch in range(start_epoch, n_epochs):
         n_mb = len(dataloader)
         for minibatch_index, minibatch in enumerate(dataloader):
-            shape = tuple(minibatch['image'].shape)
-            if group and (tuple(group[-1][2]['image'].shape) != shape or shape[0] != 1):
-                run_group(group)
-                group = []
             end_of_epoch = minibatch_index == n_mb - 1
-            group.append((epoch, minibatch_index, minibatch, end_of_epoch))
-            full = len(group) >= max_group or (counter_gradient + len(group)) % local_accum == 0
-            # a group ends with its accumulation cycle, and before a snapshot is due (the snapshot must hold exactly the
+            window.append((epoch, minibatch_index, minibatch, end_of_epoch))
+            # a window ends with its accumulation cycle, and before a snapshot is due (the snapshot must hold exactly the
             # updates up to its epoch)
-            if full or shape[0] != 1 or (end_of_epoch and is_snapshot_epoch(epoch)):
-                run_group(group)
-                group = []
-    if group:
-        run_group(group)
+            closes_cycle = (counter_gradient + len(window)) % local_accum == 0
+            if closes_cycle or len(window) >= max_window or (end_of_epoch and is_snapshot_epoch(epoch)):
+                run_window(window)
+                window = []
+    if window:
+        run_window(window)
 
     net.defer_wgrad_join = False  # joins
     net.compute_side_outputs = True

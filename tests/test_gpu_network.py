@@ -404,6 +404,59 @@ def test_grouped_micro_batches_equal_one_by_one(monkeypatch):
         print(f"[group {group}] worst delta rel-L2 vs one-by-one {max(ratios):.3e}")
 
 
+def test_mixed_frame_sizes_are_bucketed_by_shape():
+    """The reference's fine-tune draws a random scale per iteration (src/dataloaders/custom_transforms.py:63-76, wired at
+    src/util/io_helper.py:62-70): same-size frames are rarely consecutive.  `_train` buckets an accumulation cycle by shape
+    (one batched pass per shape); a loader that yields the same frames pre-sorted by shape runs the identical passes, so the
+    weights after two optimizer steps are bit-identical, and against the one-by-one order (FOSVOS_MICROBATCH_GROUP=1)
+    they agree to the gradient tolerance."""
+    import train_online
+    from util.network_provider import VGGOnlineProvider
+    sizes = {"a": (40, 70), "b": (32, 56), "c": (20, 35)}
+    order = ["a", "b", "a", "c", "b"]
+    frames = [O.synthetic_frame(1, *sizes[t], seed=230 + i) for i, t in enumerate(order)]
+    mixed = [{"image": x, "gt": gt} for x, gt in frames]
+    presorted = [mixed[i] for i in (0, 2, 1, 4, 3)]
+    seen = []
+    runs = {}
+    for tag, loader, group in (("mixed", mixed, "5"), ("presorted", presorted, "5"), ("single", mixed, "1")):
+        os.environ["FOSVOS_MICROBATCH_GROUP"] = group
+        try:
+            net, sd = make_net(27)
+            fwd = net.forward
+            shapes = []
+            net.forward = lambda x, _f=fwd, _s=shapes: (_s.append(tuple(x.shape)), _f(x))[1]
+            prov = VGGOnlineProvider.__new__(VGGOnlineProvider)
+            prov.network = net
+            prov.name = "vgg16"
+            opt = prov.get_optimizer(learning_rate=1e-8)
+            train_online.data_parallel = False
+            ret = train_online._train(prov, loader, opt, _NullWriter(), "mixed", 0, 2, 5, 10 ** 9)
+            assert ret["iterations"] == 10
+            del net.forward
+            runs[tag] = ({n_: p.detach().clone() for n_, p in net.named_parameters()}, ret["loss"], shapes, sd)
+        finally:
+            os.environ.pop("FOSVOS_MICROBATCH_GROUP", None)
+    assert runs["mixed"][2] == runs["presorted"][2] == [(2, 3, 40, 70), (2, 3, 32, 56), (1, 3, 20, 35)] * 2
+    assert len(runs["single"][2]) == 10
+    moved = 0
+    sd = runs["mixed"][3]
+    for n_ in runs["mixed"][0]:
+        assert torch.equal(runs["mixed"][0][n_], runs["presorted"][0][n_]), n_
+        d_ref = (runs["single"][0][n_] - sd[n_].to(DEV)).double().reshape(-1)
+        d_got = (runs["mixed"][0][n_] - sd[n_].to(DEV)).double().reshape(-1)
+        if float(d_ref.abs().max()) == 0.0:
+            assert float(d_got.abs().max()) == 0.0, n_
+            continue
+        ulp = float(np.spacing(np.float32(max(sd[n_].abs().max().item(), 1e-30))))
+        noise = 2 * ulp * float(np.sqrt(d_ref.numel()))
+        assert max(float((d_got - d_ref).norm()) - noise, 0.0) / float(d_ref.norm()) <= GRAD_REL_L2, n_
+        moved += 1
+    assert moved >= 30
+    # the log keeps the reference's iteration order: entry i of the bucketed run is frame i's loss
+    np.testing.assert_allclose(runs["mixed"][1], runs["single"][1], rtol=2e-2)
+
+
 def test_scheduling_switches_do_not_change_the_weights(monkeypatch):
     """What `train_online._train` does for speed only - the optimizer step split by gradient bucket (stages 5-3 stepped,
     zeroed and repacked behind the data-gradient chain, the rest behind the weight-gradient stream: FOSVOS_SPLIT_STEP) and

@@ -195,6 +195,61 @@ def test_flat_grad_buckets_of_the_real_module():
     assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
 
 
+def _mixed_frames():
+    g = torch.Generator().manual_seed(9)
+    shapes = {"A": (10, 12), "B": (8, 10), "C": (6, 14)}
+    def frame(tag):
+        h, w = shapes[tag]
+        return {"image": torch.randn(1, 3, h, w, generator=g), "gt": (torch.rand(1, 1, h, w, generator=g) > 0.7).float()}
+    return {tag + str(i): frame(tag) for tag, i in (("A", 0), ("B", 0), ("A", 1), ("C", 0), ("B", 1))}
+
+
+def test_online_loop_buckets_a_cycle_by_frame_shape(monkeypatch):
+    """The reference's augmentation draws a new scale per iteration (src/dataloaders/custom_transforms.py:63-76), so
+    same-size frames are rarely consecutive.  `_train` buckets the micro-batches of an accumulation cycle by shape and
+    runs one batched pass per shape: (i) a loader that yields the same frames already sorted by shape runs the identical
+    passes - weights bit for bit; (ii) against the one-by-one order (group size 1) the update agrees to fp32 rounding;
+    (iii) the logged losses stay in the reference's iteration order."""
+    import train_online
+    f = _mixed_frames()
+    mixed = [f[k] for k in ("A0", "B0", "A1", "C0", "B1")]
+    presorted = [f[k] for k in ("A0", "A1", "B0", "B1", "C0")]
+    passes = []
+    real_forward = TinyOSVOS.forward
+
+    def spying_forward(self, x):
+        passes.append(tuple(x.shape))
+        return real_forward(self, x)
+
+    monkeypatch.setattr(TinyOSVOS, "forward", spying_forward)
+
+    def run(loader, group):
+        monkeypatch.setenv("FOSVOS_MICROBATCH_GROUP", str(group))
+        train_online.class_balanced_cross_entropy_loss = _cbce
+        train_online.data_parallel = False
+        net = TinyOSVOS()
+        passes.clear()
+        ret = train_online._train(_Prov(net), loader, _sgd(net), _Writer(), "tiny", 0, 2, 5, 10 ** 9)
+        return net.state_dict(), ret["loss"], list(passes)
+
+    w_mixed, loss_mixed, p_mixed = run(mixed, 5)
+    w_sorted, loss_sorted, p_sorted = run(presorted, 5)
+    w_single, loss_single, p_single = run(mixed, 1)
+    assert p_mixed == p_sorted == [(2, 3, 10, 12), (2, 3, 8, 10), (1, 3, 6, 14)] * 2
+    assert len(p_single) == 10 and all(s[0] == 1 for s in p_single)
+    for k in w_mixed:
+        assert torch.equal(w_mixed[k], w_sorted[k]), k
+        assert torch.allclose(w_mixed[k], w_single[k], rtol=1e-5, atol=1e-7), k
+    # every iteration of these 2 epochs is a logging point (src/train_online.py:84-90): the trace of the bucketed run equals
+    # the one-by-one trace ENTRY BY ENTRY - the passes ran bucket by bucket, the log follows the reference's iteration order
+    assert len(loss_mixed) == len(loss_single) == 10
+    assert torch.allclose(torch.tensor(loss_mixed), torch.tensor(loss_single), rtol=1e-5)
+    # frames A0 B0 A1 C0 B1 -> presorted order A0 A1 B0 B1 C0
+    perm = [0, 2, 1, 4, 3]
+    assert torch.allclose(torch.tensor(loss_sorted[:5]), torch.tensor([loss_mixed[i] for i in perm]), rtol=1e-5)
+    assert loss_mixed[0] != loss_mixed[1]
+
+
 def test_flat_grad_bucket_ids_with_a_frozen_stage():
     """A slice of the flat buffer keeps the NATIVE bucket id of its gradients (what fosvos_vgg_grad_bucket_wait takes): with
     stage 4 frozen, slice 0 is bucket 1, and a tensor outside every bucket waits for the pass's last bucket."""
