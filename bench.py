@@ -12,16 +12,28 @@ One "step" = one iteration of the reference's online loop body (src/train_online
 backward -> fused SGD step + zero_grad every 5th iteration.  It runs through the drop-in ``train_online._train`` with
 the drop-in ``OSVOS_VGG`` module, i.e. the shipped path (native layer loop, two-stream backward, deferred wgrad join).
 
-N > 1, one process per GPU over RCCL.  Two mappings of BASELINE.json configs[3] are timed in the same run:
+N > 1, one process per GPU over RCCL.  Three mappings of BASELINE.json configs[3] are timed in the same run:
   dp        (``value``) every rank runs the same K steps on its own frames and the flat fp32 gradient buffer is
             SUM-all-reduced (bucketed, overlapped with the backward pass) before each optimizer step: weak scaling,
             5 local micro-batches per rank and step
+  dp_strict (``dp_strict`` object) the parity-preserving split of ONE sequence's fine-tune (SURVEY.md section 8(e)(ii),
+            src/train_online.py:92-101): world x local_accum = avg_grad_every_n, with avg_grad_every_n the smallest
+            multiple of the world size >= 5 (8 ranks: 8, one micro-batch per rank and optimizer step) - the mode in which
+            the 59.7 MB all-reduce has to hide behind ONE frame per rank
   replicas  (``replicas`` object) N independent sequences, no collective: the reference's own -sg/-sgs sharding
             (src/train_online.py:178-189), the parity-preserving mapping
 The line carries ``backend``, ``ranks`` and ``distinct_devices``; ``n_gpus`` is the number of DISTINCT devices, and
 the nccl backend is refused when two ranks share one (a gloo rehearsal of two ranks on one GPU reads n_gpus 1).
 
-Extra objects on the one JSON line rank 0 prints:
+Extra objects on the one JSON line rank 0 prints (N = 1):
+  cold            the same K steps behind the W warm-up steps only (no preconditioning): what a short window measures on a
+                  device that is still raising its clocks; timed FIRST, right after the model is built
+  group1          one frame per pass (FOSVOS_MICROBATCH_GROUP=1: the reference's one-by-one order, and what a cycle of five
+                  different frame sizes degenerates to)
+  mixed_scales    the reference's real augmentation: frames drawn from {1.0, 0.8, 0.5} x 480x854 with a fixed seed
+                  (src/dataloaders/custom_transforms.py:63-76), bucketed by shape inside each accumulation cycle
+  offline         BASELINE.json configs[2]: train_offline._train on batches of 16 x 480x854 frames, five deeply supervised
+                  losses, avg_grad_every_n = 10 (src/train_offline.py:77-110)
   roofline        MFMA roofline of the conv3x3 kernels (k_conv3x3_igemm forward + data gradient, k_wgrad3x3 weight
                   gradient): per-launch durations from HIP events recorded by the library around every kernel ON ITS
                   OWN LAUNCH STREAM (fosvos_profile_start/stop), over `--prof-steps` further steps of the same shipped
@@ -58,8 +70,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", choices=["both", "dp", "replicas"], default="both",
-                    help="N > 1: which mapping(s) to time; `value` is dp unless only replicas is asked for")
+    ap.add_argument("--mode", choices=["both", "dp", "dp_strict", "replicas"], default="both",
+                    help="N > 1: which mapping(s) to time (both = dp, dp_strict and replicas); `value` is dp unless only "
+                         "another one is asked for")
+    ap.add_argument("--no-variants", action="store_true", help="skip the cold / group1 / mixed_scales / offline objects")
+    ap.add_argument("--offline-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
@@ -119,6 +134,56 @@ def cpu_baseline(iters: int):
     return {"value": iters / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"2 warm-up + {iters} timed fwd+loss+bwd iterations (SGD step every {AVG_GRAD_EVERY_N}th) at "
                       f"1x3x{H}x{W} fp32 (oracle/osvos_ref.py, torch {torch.__version__} CPU), {dt / iters * 1000:.0f} ms/iter"}
+
+
+def offline_config(args, dev, make_frame, barrier):
+    """BASELINE.json configs[2]: train_offline._train itself on resident batches of 16 synthetic 480x854 frames, five deeply
+    supervised losses, avg_grad_every_n = 10 (src/train_offline.py:77-110).  One epoch = 10 iterations = one optimizer
+    step; 1 warm-up epoch, 2 timed epochs."""
+    import torch
+    import train_offline
+    from networks.osvos_vgg import OSVOS_VGG
+    from util.network_provider import VGGOfflineProvider
+    nb = args.offline_batch
+    torch.manual_seed(4321)
+    net = OSVOS_VGG(pretrained=0)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if name.startswith("upscale"):
+                continue
+            if p.dim() == 4:
+                fan_in = p.shape[1] * p.shape[2] * p.shape[3]
+                p.normal_(0, (2.0 / fan_in) ** 0.5 if name.startswith("stages") else (1.0 / fan_in) ** 0.5)
+            else:
+                p.normal_(0, 0.1)
+    prov = VGGOfflineProvider.__new__(VGGOfflineProvider)
+    prov.network = net.to(dev)
+    prov.name = "vgg16"
+    opt = prov.get_optimizer()
+    frames = [make_frame(H, W, seed=4321, index=i) for i in range(nb)]
+    batch = {"image": torch.stack([f[0] for f in frames]).to(dev), "gt": torch.stack([f[1] for f in frames]).to(dev)}
+    accum, timed_epochs = 10, 2
+    loader = [batch] * accum
+    train_offline.data_parallel = False
+
+    def run(first_epoch, n):
+        return train_offline._train(prov, loader, None, opt, _NullWriter(), first_epoch, first_epoch + n, accum, 10 ** 9, False, 5)
+
+    run(0, 1)
+    barrier()
+    t0 = time.perf_counter()
+    ret = run(1, timed_epochs)
+    barrier()
+    e = time.perf_counter() - t0
+    iters = ret["iterations"]
+    conv_flop = 773.27e9 * nb  # SURVEY.md section 8(d): fwd + dgrad + wgrad of the 3x3 convs per 480x854 frame
+    return {"value": iters * nb / e, "unit": "frames/s", "ms_per_step": e / iters * 1000.0, "iterations": iters,
+            "batch": nb, "avg_grad_every_n": accum, "losses": 5,
+            "step_wall_tflops": conv_flop * iters / e / 1e12,
+            "step_wall_frac": conv_flop * iters / e / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            "workload": f"train_offline._train: {nb}x3x{H}x{W} per iteration, five class-balanced BCE losses "
+                        f"((1 - epoch/n_epochs) * side losses + fused), backward, fused SGD step every {accum} iterations "
+                        f"(BASELINE.json configs[2]); one iteration is one step"}
 
 
 def main():
@@ -192,27 +257,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(mode):
+    def strict_avg():
+        """avg_grad_every_n of the strict split: the smallest multiple of the world size that is >= the reference's 5."""
+        return world * -(-AVG_GRAD_EVERY_N // world)
+
+    def timed(mode, precondition=PRECONDITION_STEPS, loader=None, env=None):
         """W warm-up + exactly K timed steps of `mode`, barrier + device sync on both sides, MAX over ranks."""
         prov, opt = make_provider()
-        train_online.data_parallel = world > 1 and mode == "dp"
-        accum = AVG_GRAD_EVERY_N * (world if train_online.data_parallel else 1)  # 5 local micro-batches per rank
+        train_online.data_parallel = world > 1 and mode in ("dp", "dp_strict")
+        if mode == "dp_strict":
+            accum = strict_avg()  # world x local_accum = avg_grad_every_n: the single-process update, split over the ranks
+        else:
+            accum = AVG_GRAD_EVERY_N * (world if train_online.data_parallel else 1)  # 5 local micro-batches per rank
+        frames = loader if loader is not None else batch
+        saved_env = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
 
         def run(n_steps):
-            return train_online._train(prov, batch, opt, _NullWriter(), "bench", 0, n_steps, accum, 10 ** 9)
+            if n_steps <= 0:
+                return {}
+            n_epochs, rest = divmod(n_steps, len(frames))
+            assert rest == 0, (n_steps, len(frames))
+            return train_online._train(prov, frames, opt, _NullWriter(), "bench", 0, n_epochs, accum, 10 ** 9)
 
         # Device wake-up, in front of the W warm-up steps (untimed, declared in the JSON line): after an idle gap - process
         # start-up, model construction - the device's clocks take a few milliseconds of load to come up, which a short timed
         # window would otherwise measure (tools/train_call_probe.py: 20 steps take 19.2 ms after 300 ms of idle, 17.4 ms
-        # right behind another call).  The same workload, PRECONDITION_STEPS steps of it.
-        if PRECONDITION_STEPS > 0:
-            run(PRECONDITION_STEPS)
-        run(args.warmup)
-        barrier()
-        t0 = time.perf_counter()
-        ret = run(args.steps)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        # right behind another call).  The same workload, `precondition` steps of it.
+        try:
+            run(precondition)
+            run(args.warmup)
+            barrier()
+            t0 = time.perf_counter()
+            ret = run(args.steps)
+            barrier()
+            elapsed = time.perf_counter() - t0
+        finally:
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         host_lead[mode] = ret.get("seconds_host_enqueue")
         if world > 1:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -222,8 +307,12 @@ def main():
         return elapsed, prov, opt, run
 
     host_lead = {}  # per mode: seconds the host loop needed to ENQUEUE the timed steps (the device finishes later)
-    modes = ["single"] if world == 1 else (["dp", "replicas"] if args.mode == "both" else [args.mode])
+    modes = ["single"] if world == 1 else (["dp", "dp_strict", "replicas"] if args.mode == "both" else [args.mode])
     results = {}
+    cold = None
+    if world == 1 and not args.no_variants:
+        # FIRST, on the device as the start-up of the process left it: W warm-up steps, K timed steps, no preconditioning
+        cold = timed("cold", precondition=0)[0]
     for m in modes:
         results[m] = timed(m)
     head = modes[0]
@@ -235,6 +324,10 @@ def main():
         if m == "dp":
             return (f"dp{world}: 5 local micro-batches per rank and step, bucketed fp32 gradient all-reduce (59.7 MB per "
                     f"optimizer step, {backend}) overlapped with the backward pass")
+        if m == "dp_strict":
+            return (f"dp{world} strict: avg_grad_every_n = {strict_avg()} split over {world} ranks ({strict_avg() // world} "
+                    f"micro-batch(es) per rank and optimizer step): the update of one process running all of them "
+                    f"(SURVEY.md section 8(e)(ii)); bucketed all-reduce over {backend} behind every pass that closes a cycle")
         return f"{world} independent replicas (one sequence per rank, src/train_online.py:178-189), no collective"
 
     out = {
@@ -267,6 +360,37 @@ def main():
         e = results[m][0]
         out[m] = {"value": args.steps * world / e, "unit": "frames/s", "ms_per_step": e / args.steps * 1000.0,
                   "parallelism": parallelism(m)}
+    if cold is not None:
+        out["cold"] = {"value": args.steps / cold, "unit": "frames/s", "ms_per_step": cold / args.steps * 1000.0,
+                       "note": f"the same {args.steps} steps behind {args.warmup} warm-up steps only, timed first (no preconditioning)"}
+    if world == 1 and not args.no_variants:
+        # one frame per pass: the reference's own order, and the worst case of the shape bucketing
+        e = timed("group1", env={"FOSVOS_MICROBATCH_GROUP": "1"})[0]
+        out["group1"] = {"value": args.steps / e, "unit": "frames/s", "ms_per_step": e / args.steps * 1000.0,
+                         "note": "FOSVOS_MICROBATCH_GROUP=1: every micro-batch its own forward / backward pass"}
+        # the reference's augmentation: a random scale per iteration, fixed seed; 20 frames per epoch
+        import random
+        rng = random.Random(1234)
+        scales = [rng.choice((1.0, 0.8, 0.5)) for _ in range(20)]
+        mixed = []
+        for i, sc in enumerate(scales):
+            hh, ww = int(H * sc), int(W * sc)  # cv2.resize(fx=fy=sc) sizes: 480x854, 384x683, 240x427
+            im, g = make_frame(hh, ww, seed=1234, index=i)
+            mixed.append({"image": im.unsqueeze(0).to(dev), "gt": g.unsqueeze(0).to(dev)})
+        saved_steps, saved_warm = args.steps, args.warmup
+        args.steps, args.warmup = 100, 20
+        try:
+            e = timed("mixed", precondition=40, loader=mixed)[0]
+        finally:
+            args.steps, args.warmup = saved_steps, saved_warm
+        px = sum(b["image"].shape[2] * b["image"].shape[3] for b in mixed) / len(mixed)
+        out["mixed_scales"] = {"value": 100 / e, "unit": "frames/s", "ms_per_step": e / 100 * 1000.0, "steps": 100,
+                               "scales": {str(k): scales.count(k) for k in (1.0, 0.8, 0.5)},
+                               "mean_pixels_per_frame": px, "full_frame_equivalents_per_s": 100 / e * px / (H * W),
+                               "note": "frames drawn from {1.0, 0.8, 0.5} x 480x854 (seed 1234, 20 per epoch), bucketed by "
+                                       "shape inside each accumulation cycle of 5 (src/dataloaders/custom_transforms.py:63-76)"}
+        del mixed
+        out["offline"] = offline_config(args, dev, make_frame, barrier)
 
     if rank == 0 and not args.no_roofline:
         # rank-0-only pass, so no collective: the single-process loop (what every replica runs; the dp loop differs only by

@@ -18,10 +18,10 @@ cd /tmp && export TMPDIR=/tmp
 # the profiled runs skip bench.py's device wake-up steps: the step counts in the summaries stay 80 (10 + 50 + 20) and 25 (5 + 20)
 export FOSVOS_BENCH_PRECONDITION=0
 echo "== kernel stats"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-infer > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-infer --no-variants > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
 echo "== pmc traffic"
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-infer --no-roofline > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || exit 1
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-infer --no-roofline > $OUT/pmc_write.json 2> $OUT/pmc_write.err || exit 1
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-infer --no-roofline --no-variants > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || exit 1
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-infer --no-roofline --no-variants > $OUT/pmc_write.json 2> $OUT/pmc_write.err || exit 1
 echo "== pmc sq"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "GRBM_GUI_ACTIVE SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD"; do
