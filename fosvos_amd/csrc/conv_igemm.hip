@@ -138,6 +138,9 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     uint4 *sA = smem;
     uint4 *sB = smem + T::A_SLOTS;
+#ifdef FOSVOS_IGEMM_PRIO
+    __builtin_amdgcn_s_setprio(FOSVOS_IGEMM_PRIO);  // lab build: these waves win the SIMD's arbitration against the weight-gradient waves beside them
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

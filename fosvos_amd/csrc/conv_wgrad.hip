@@ -45,6 +45,7 @@ struct WgArgs {
     unsigned long long *stamps;  // diagnostic build only (tools/wgrad_stamp_lab.hip): 8 sums per workgroup
 #endif
     int lab;  // timing-only switches (FOSVOS_WGRAD_LAB; wrong results): 1 no slab store, 2 loads from the zero page
+    int S, n_ci, n_co, xcd_order;  // v2: 1-D grid of S * n_ci * n_co workgroups, decoded in the kernel (see there)
 };
 
 typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_ptr;
@@ -364,6 +365,292 @@ __global__ __launch_bounds__(64 * WCO * WCI) __attribute__((amdgpu_waves_per_eu(
 #endif
 }
 
+// =====================================================================================================================
+// Round 3 form of the MFMA kernel for the backbone layers (Co % 64 == 0): same tile (8 x 16 pixels of dy, 10 x 18 halo of
+// x), same grid, same slabs - rebuilt around three measurements of the form above (1 wave per SIMD, 280 registers, 33-35 % of
+// the MFMA cycles when alone on the chip, 25 % of its wave cycles in s_waitcnt / s_barrier):
+//   * staging is LDS-DMA (buffer_load ... lds): the next tile goes from L2 straight into the other LDS image while the
+//     MFMA loop runs - no staging registers (-40), no ds_write, nothing to wait for behind the loop but the DMA itself;
+//     pieces are 8 pixels x 128 B, i.e. whole 128-byte lines of the NHWC tensors;
+//   * 8 waves per workgroup, two per SIMD, each 32 co x 16 ci x 9 taps on v_mfma_f32_16x16x32_bf16 (18 accumulators of 4
+//     registers): ~150 registers per wave, so one of these workgroups and one 192-register igemm workgroup still share a CU;
+//   * the bias gradient (column sums of dy) is one extra MFMA against a vector of ones, taken in turn by the waves.
+// LDS image of a tile: [pixel][128 B = 64 channels], 16-byte chunk c of pixel px stored at chunk slot c ^ 2((px >> 1) & 3).
+// An LDS-DMA instruction writes lane i's 16 bytes at base + 16 i, so the swizzle is applied to the SOURCE address; the
+// transposed reads apply the same XOR.  Row strides (16 px for dy, 24 px for the x halo: 18 used) are multiples of 8 px, so
+// the XOR term of a lane's address does not change from row to row.  With it a 32-lane half of a ds_read_b64_tr_b16 covers
+// 8 consecutive pixels x 32 B on 64 distinct banks for every tap shift (simulated with the bank rule of the guide).
+// k index of an MFMA (32 pixels): lane group g, element j  <->  tile row r + 4 (g >> 1), pixel 4 (g & 1) + (j & 3) + 8 (j >> 2):
+// any bijection does as long as both operands use the same one - this one makes the halves of a read contiguous.
+// The loop walks R = 0..5: the x fragments of halo rows (R, R + 4) meet the dy fragments of tile rows (R - ky, R + 4 - ky).
+#ifndef FOSVOS_W2_PPR
+#define FOSVOS_W2_PPR 2  // staging pieces per row of the MFMA loop (lab: 3 = all six in the first two rows)
+#endif
+namespace v2 {
+constexpr int XROW = 24;                          // pixels per halo row in LDS (18 used)
+constexpr int Y_BYTES = TPIX * 128;               // 16 KB
+constexpr int X_BYTES = (TH + 2) * XROW * 128;    // 30 KB
+constexpr int BUF_BYTES = Y_BYTES + X_BYTES;
+constexpr int LDS_BYTES = 2 * BUF_BYTES;          // 92 KB: two tile images
+constexpr int NT = 512;
+constexpr int Y_PIECES = TPIX / 8, X_PIECES = (TH + 2) * XROW / 8;   // 16 + 30 pieces of 1 KB per tile
+constexpr int N_IT = (Y_PIECES + X_PIECES + 7) / 8;                   // pieces per wave (6; waves 6, 7 issue 5)
+static_assert(Y_PIECES == 16 && X_PIECES == 30 && N_IT == 6, "piece schedule below");
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ bf16x8 tr_pair16(const char *p) {  // 8 pixels of one channel: p .. +3, then 8 pixels on (+1024 B)
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 1024));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// One LDS-DMA instruction, hidden from the compiler: with the builtin form hipcc cannot tell the image being filled from
+// the image being read and puts s_waitcnt vmcnt(0) in front of the first transposed read of every tile, which serialises the
+// DMA with the MFMA loop.  M0 carries the LDS destination (wave-uniform); lane i's 16 bytes land at M0 + 16 i.  The wave
+// waits for its own DMA (s_waitcnt vmcnt(0), also inline) in front of the barrier that publishes the image.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigned lds_dst, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wgrad3x3_v2(const WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_w[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 2, wi = wave & 3;          // 32-co block, 16-ci block of this wave
+    // Workgroup -> (pixel split, ci block, co block).  The n_ci * n_co workgroups of a split walk the same tiles: each x slice
+    // is read by n_co of them, each dy slice by n_ci.  The dispatcher deals consecutive workgroup ids round-robin over the 8
+    // XCDs (each with its own L2), so with a plain 3-D grid the workgroups that share operands never meet in an L2 and every
+    // slice is fetched from beyond L2 once per reader (measured: the kernel moved 2x its algorithmic bytes and did not get
+    // faster when its staging stalls were removed).  Remapped - a speed choice, never correctness: the ids that share an XCD
+    // (id % 8) take one contiguous eighth of the (split, ci, co) space, co fastest, and start together.
+    int bid = blockIdx.x;
+    if (a.xcd_order) {
+        const int n_wg = gridDim.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = bid & 7;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);  // bijective for any n_wg
+    }
+    const int co_blk = bid % a.n_co, ci_blk = (bid / a.n_co) % a.n_ci, split = bid / (a.n_co * a.n_ci);
+    const int ci0 = ci_blk * 64, co0 = co_blk * 64;
+    const int H = a.H, W = a.W;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)smem_w);
+
+    f32x4 acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[2] = {0.f, 0.f};  // bias gradient: this lane's share (its 8 pixels of a k-step) of sum over pixels of dy[., co]
+
+    // ---- transposed-read addresses of this lane (bytes inside a tile image)
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int pxl = 4 * (g & 1) + q;                                   // pixel inside the row, first read
+    auto swz = [](int px, int c) { return (c ^ (2 * ((px >> 1) & 3))) * 16; };
+    int rd_y[2], rd_x[3];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        rd_y[u] = ((4 * (g >> 1)) * 16 + pxl) * 128 + swz(pxl, 2 * (2 * wc + u) + (p >> 1)) + (p & 1) * 8;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+        rd_x[kx] = Y_BYTES + ((4 * (g >> 1)) * XROW + pxl + kx) * 128 + swz(pxl + kx, 2 * wi + (p >> 1)) + (p & 1) * 8;
+
+    // ---- staging plan: piece pc = 8 it + wave; pieces 0..15 are dy, 16..45 x.  Lane i fetches the 16 bytes that belong at
+    // LDS offset 1024 pc' + 16 i: pixel 8 pc' + (i >> 3), chunk slot i & 7 -> source chunk (i & 7) ^ swizzle(pixel).
+    // The two dy pieces of a wave are 4 tile rows apart (same columns): one offset register serves both.
+    const int ppx = lane >> 3, slot = lane & 7;
+    unsigned goff_y, goff_x[N_IT - 2];
+    {
+        const int pix = wave * 8 + ppx, ty = pix >> 4, tx = pix & 15;
+        goff_y = (unsigned)(((ty * W + tx) * a.Cy + co0 + (slot ^ (2 * ((tx >> 1) & 3))) * 8) * 2);
+    }
+#pragma unroll
+    for (int it = 2; it < N_IT; ++it) {
+        const int pix = ((it - 2) * 8 + wave) * 8 + ppx, hy = pix / XROW, hx = pix - hy * XROW;
+        const bool used = (it - 2) * 8 + wave < X_PIECES && hx < HALO_W;
+        goff_x[it - 2] = used ? (unsigned)(((hy * W + hx) * a.Ci + ci0 + (slot ^ (2 * ((hx >> 1) & 3))) * 8) * 2) : ~0u;
+    }
+    const unsigned y_step = (unsigned)(4 * W * a.Cy * 2);  // dy piece it = 1: four tile rows further
+    const int64_t halo_shift = (int64_t)(W + 1) * a.Ci;
+    const unsigned y_total = (unsigned)((int64_t)a.N * H * W * a.Cy * 2), x_total = (unsigned)(((int64_t)a.N * H * W * a.Ci + halo_shift) * 2);
+    const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.dy), 0, y_total, 0x00020000);
+    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.x) - halo_shift, 0, x_total, 0x00020000);
+
+    const int t_begin = split * a.tiles_per_split;
+    const int t_end = min(t_begin + a.tiles_per_split, a.n_tiles);
+    int lt_x = t_begin % a.tiles_x, lt_y = (t_begin / a.tiles_x) % a.tiles_y, lt_n = t_begin / (a.tiles_x * a.tiles_y);
+
+    // DMA of tile (lt_x, lt_y, lt_n) into the image at LDS offset `img_`; out-of-image pieces read offset ~0 = zeros (the
+    // descriptor's range check).  Edge tiles re-derive a piece's (row, column) from the lane: no registers held for it.
+#define FOSVOS_W2_PIECE_Y(it_, img_)                                                                            \
+    {                                                                                                           \
+        unsigned v_ = goff_y + (it_) * y_step;                                                                  \
+        if (!interior_) {                                                                                       \
+            const int pix_ = ((it_) * 8 + wave) * 8 + ppx;                                                      \
+            v_ = ((pix_ >> 4) < vrows_ && (pix_ & 15) < vcols_) ? v_ : ~0u;                                     \
+        }                                                                                                       \
+        dma16(y_rsrc, (img_) + ((it_) * 8 + wave) * 1024, v_, ysoff_);                                          \
+    }
+#define FOSVOS_W2_PIECE_X(it_, img_)                                                                            \
+    if ((it_) < N_IT - 1 || wave < 6) {                                                                         \
+        unsigned v_ = goff_x[(it_) - 2];                                                                        \
+        if (!interior_) {                                                                                       \
+            const int pix_ = (((it_) - 2) * 8 + wave) * 8 + ppx, hy_ = pix_ / XROW, hx_ = pix_ - hy_ * XROW;    \
+            v_ = (hy_ >= 1 - y0_ && hy_ <= vrows_ && hx_ >= 1 - x0_ && hx_ <= vcols_) ? v_ : ~0u;               \
+        }                                                                                                       \
+        dma16(x_rsrc, (img_) + Y_BYTES + (((it_) - 2) * 8 + wave) * 1024, v_, xsoff_);                          \
+    }
+#define FOSVOS_W2_TILE_SCALARS()                                                                                \
+    const int y0_ = lt_y * TH, x0_ = lt_x * 16;                                                                 \
+    const int vrows_ = H - y0_, vcols_ = W - x0_;                                                               \
+    const int64_t org_ = ((int64_t)lt_n * H + y0_) * W + x0_;                                                   \
+    const unsigned ysoff_ = (unsigned)(org_ * a.Cy * 2), xsoff_ = (unsigned)(org_ * a.Ci * 2);                  \
+    const bool interior_ = y0_ >= 1 && y0_ + TH < H && x0_ >= 1 && x0_ + 16 < W;
+#define FOSVOS_W2_ADVANCE()                                                                                     \
+    if (++lt_x == a.tiles_x) {                                                                                  \
+        lt_x = 0;                                                                                               \
+        if (++lt_y == a.tiles_y) { lt_y = 0; ++lt_n; }                                                          \
+    }
+#define FOSVOS_W2_STAGE(img_)                                                                                   \
+    {                                                                                                           \
+        FOSVOS_W2_TILE_SCALARS()                                                                                \
+        FOSVOS_W2_PIECE_Y(0, img_) FOSVOS_W2_PIECE_Y(1, img_)                                                   \
+        FOSVOS_W2_PIECE_X(2, img_) FOSVOS_W2_PIECE_X(3, img_) FOSVOS_W2_PIECE_X(4, img_) FOSVOS_W2_PIECE_X(5, img_) \
+        FOSVOS_W2_ADVANCE()                                                                                     \
+    }
+    // piece `it_` of the next tile, issued from inside the MFMA loop (one per row: see there)
+#define FOSVOS_W2_PIECE(it_, img_)                                                                              \
+    if (has_next) {                                                                                             \
+        if constexpr ((it_) < 2) { FOSVOS_W2_PIECE_Y(it_, img_) } else { FOSVOS_W2_PIECE_X(it_, img_) }         \
+    }
+
+    if (t_begin < t_end) FOSVOS_W2_STAGE(lds0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA has landed ...
+    __syncthreads();                                   // ... and everyone's
+
+    const bool do_bias = a.bias_part != nullptr;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    // sum of the 8 bf16 of a fragment into `acc_` (v_dot2c_f32_bf16 against (1, 1): two elements per instruction)
+    auto add8 = [](const bf16x8 &f, float acc_) {
+        const bf16x2_t one2 = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+        acc_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), one2, acc_, false);
+        acc_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), one2, acc_, false);
+        acc_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), one2, acc_, false);
+        acc_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), one2, acc_, false);
+        return acc_;
+    };
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int par = (tile - t_begin) & 1;
+        const char *cur = smem_w + par * BUF_BYTES;
+        // The other image was last read during tile - 1 and every wave has passed that tile's barrier, so the next tile's DMA
+        // may start now.  Its six pieces are NOT issued in one burst: an LDS-DMA instruction holds its wave for ~60-180
+        // clocks while the memory pipe takes it in, and eight waves bursting together left the matrix pipe idle for the
+        // first ~1000 clocks of every tile.  Two pieces ride in front of each of the first three rows; the last ones then
+        // have the other three rows of matrix work (half the tile) to land under before the wave waits for them.
+        const bool has_next = tile + 1 < t_end;
+        const unsigned nxt_ = lds0 + (par ^ 1) * BUF_BYTES;
+        FOSVOS_W2_TILE_SCALARS()
+        // the bias sums of a tile are taken by one ci block of the grid and, inside it, by one of the four ci waves in turn
+        const bool my_bias = do_bias && (tile % a.n_ci) == ci_blk && ((tile / a.n_ci) & 3) == wi;
+
+        const char *yb0 = cur + rd_y[0], *yb1 = cur + rd_y[1];
+        const char *xb0 = cur + rd_x[0], *xb1 = cur + rd_x[1], *xb2 = cur + rd_x[2];
+        bf16x8 a0[2], a1[2], a2[2], b[3], bn[3];
+        a0[0] = a0[1] = a1[0] = a1[1] = a2[0] = a2[1] = bn[0] = bn[1] = bn[2] = bf16x8{};
+        b[0] = tr_pair16(xb0);
+        b[1] = tr_pair16(xb1);
+        b[2] = tr_pair16(xb2);
+        // Row R: the dy fragments of row R are requested in front of the row's MFMAs and used by its LAST six (ky = 0); the x
+        // fragments of row R + 1 are requested behind the first six (ky = 2), whose dy registers they may then take, and have
+        // the other twelve to land under: every request has matrix work of this very wave to cover it (the two waves of a SIMD run in lockstep - same program, one
+        // barrier per tile - and do not cover each other's LDS latency).  A compiler fence per row keeps the reads in their row.
+#define FOSVOS_W2_ROW(R)                                                                                        \
+        {                                                                                                           \
+            a2[0] = a1[0]; a2[1] = a1[1]; a1[0] = a0[0]; a1[1] = a0[1];                                             \
+            if constexpr (FOSVOS_W2_PPR == 2 && (R) < 3) { FOSVOS_W2_PIECE(2 * (R), nxt_) FOSVOS_W2_PIECE(2 * (R) + 1, nxt_) } \
+            if constexpr (FOSVOS_W2_PPR == 3 && (R) < 2) {                                                          \
+                FOSVOS_W2_PIECE(3 * (R), nxt_) FOSVOS_W2_PIECE(3 * (R) + 1, nxt_) FOSVOS_W2_PIECE(3 * (R) + 2, nxt_) } \
+            if constexpr ((R) < 4) {                                                                                \
+                a0[0] = tr_pair16(yb0 + (R) * 16 * 128);                                                            \
+                a0[1] = tr_pair16(yb1 + (R) * 16 * 128);                                                            \
+            }                                                                                                       \
+            if constexpr ((R) >= 2) {                                                                               \
+                _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                    \
+                _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                       \
+                    acc[6 + kx][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[u], b[kx], acc[6 + kx][u], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);  /* the registers of a2 are free from here: the next reads may take them */ \
+            }                                                                                                       \
+            if constexpr ((R) + 1 < 6) {                                                                            \
+                bn[0] = tr_pair16(xb0 + ((R) + 1) * XROW * 128);                                                    \
+                bn[1] = tr_pair16(xb1 + ((R) + 1) * XROW * 128);                                                    \
+                bn[2] = tr_pair16(xb2 + ((R) + 1) * XROW * 128);                                                    \
+            }                                                                                                       \
+            if constexpr ((R) >= 1 && (R) <= 4) {                                                                   \
+                _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                    \
+                _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                       \
+                    acc[3 + kx][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u], b[kx], acc[3 + kx][u], 0, 0, 0); \
+            }                                                                                                       \
+            if constexpr ((R) < 4) {                                                                                \
+                _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                    \
+                _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                       \
+                    acc[kx][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[u], b[kx], acc[kx][u], 0, 0, 0);        \
+                if (my_bias) {                                                                                      \
+                    bsum[0] = add8(a0[0], bsum[0]);                                                                 \
+                    bsum[1] = add8(a0[1], bsum[1]);                                                                 \
+                }                                                                                                   \
+            }                                                                                                       \
+            asm volatile("" ::: "memory");                                                                          \
+            b[0] = bn[0]; b[1] = bn[1]; b[2] = bn[2];                                                               \
+        }
+        FOSVOS_W2_ROW(0) FOSVOS_W2_ROW(1) FOSVOS_W2_ROW(2) FOSVOS_W2_ROW(3) FOSVOS_W2_ROW(4) FOSVOS_W2_ROW(5)
+        if (has_next) FOSVOS_W2_ADVANCE()
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile + 1: this wave's DMA has landed ...
+        __syncthreads();                                   // ... everyone's has, and image `cur` is retired
+    }
+
+    // ---- bias partials: lane (g, i) of wave (wc, wi) holds, for channel 32 wc + 16 u + i, the sum over its quarter of the
+    // k index (group g) of the tiles that wave took: 16 partials per channel, added in a fixed order
+    if (do_bias) {
+        float *sb = reinterpret_cast<float *>(smem_w);  // [4 wi][4 g][64 co]
+#pragma unroll
+        for (int u = 0; u < 2; ++u) sb[(wi * 4 + g) * 64 + wc * 32 + u * 16 + (lane & 15)] = bsum[u];
+        __syncthreads();
+        if (tid < 64 && co0 + tid < a.Cor) {
+            float acc_b = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc_b += sb[k * 64 + tid];
+            a.bias_part[((int64_t)split * a.n_ci + ci_blk) * a.Cor + co0 + tid] = acc_b;
+        }
+    }
+    // ---- slab write, laid out like dw (OIHW): register r of accumulator (t, u) of lane l is
+    //   co = co0 + 32 wc + 16 u + 4 (l >> 4) + r,  ci = ci0 + 16 wi + (l & 15),  tap t: the 9 taps of an element are contiguous
+    float *slab = a.slabs + (int64_t)split * a.Cor * a.Ci * 9;
+    const int ci = ci0 + wi * 16 + (lane & 15);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wc * 32 + u * 16 + 4 * g + r;
+            if (co >= a.Cor || (a.lab & 1)) continue;
+            float *d = slab + ((int64_t)co * a.Ci + ci) * 9;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) d[t] = acc[t][u][r];
+        }
+#undef FOSVOS_W2_ROW
+#undef FOSVOS_W2_PIECE
+#undef FOSVOS_W2_TILE_SCALARS
+#undef FOSVOS_W2_ADVANCE
+#undef FOSVOS_W2_STAGE
+#undef FOSVOS_W2_PIECE_X
+#undef FOSVOS_W2_PIECE_Y
+}
+}  // namespace v2
+
 // ---- reduction over splits for MANY layers per launch, two coalesced stages, every sum in a fixed order
 // stage A (layers with more than kFold splits): slab 8j += slabs 8j+1 .. 8j+7, in place - one thread per float4 and
 // group, so the early layers (few elements, hundreds of splits) spread over thousands of threads instead of a few dozen
@@ -454,6 +741,11 @@ int wgrad_waves() {  // FOSVOS_WGRAD_WAVES=8: 128 co x 64 ci eight-wave workgrou
         return e && atoi(e) == 8 ? 8 : 4;
     }();
     return v;
+}
+
+bool wgrad_v2() {  // FOSVOS_WGRAD_V2=0: the round-2 kernel (lab switch, read at every call so that one process can A/B)
+    const char *e = getenv("FOSVOS_WGRAD_V2");
+    return !(e && atoi(e) == 0);
 }
 
 struct Plan {
@@ -598,6 +890,7 @@ int fosvos::wgrad_impl(const uint16_t *x, const uint16_t *dy, float *dw, float *
     a.bias_part = db ? reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + p.slab_bytes) : nullptr;
     a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Cy = p.Cy; a.Cor = p.Cor;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles; a.tiles_per_split = p.tps;
+    a.S = p.S; a.n_ci = a.n_co = 0; a.xcd_order = 0;
     {
         static const int lab = getenv("FOSVOS_WGRAD_LAB") ? atoi(getenv("FOSVOS_WGRAD_LAB")) : 0;
         a.lab = lab;
@@ -605,7 +898,7 @@ int fosvos::wgrad_impl(const uint16_t *x, const uint16_t *dy, float *dw, float *
 #ifdef FOSVOS_WG_STAMP
     a.stamps = g_wg_stamps;
 #endif
-    static bool once[64][3];  // per device: opt in to the dynamic LDS size
+    static bool once[64][4];  // per device: opt in to the dynamic LDS size
     const double flops = 2.0 * N * H * W * 9.0 * Ci * Co;
     if (p.wide) {
         using C = Cfg<4, 2>;
@@ -617,6 +910,20 @@ int fosvos::wgrad_impl(const uint16_t *x, const uint16_t *dy, float *dw, float *
         const dim3 grid((unsigned)p.S, (unsigned)(Ci / C::BCIW), (unsigned)(p.Cor / C::BCO));
         FOSVOS_PROF("k_wgrad3x3<4, 2>", st, flops);
         hipLaunchKernelGGL((k_wgrad3x3<4, 2>), grid, dim3(C::NT), C::LDS_BYTES, st, a);
+    } else if (!p.side && wgrad_v2()) {
+        if (device >= 0 && device < 64 && !once[device][3]) {
+            FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(v2::k_wgrad3x3_v2),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, v2::LDS_BYTES));
+            once[device][3] = true;
+        }
+        a.S = p.S; a.n_ci = Ci / 64; a.n_co = p.Cor / 64;
+        {
+            const char *e = getenv("FOSVOS_WGRAD_XCD");  // lab switch: 0 = plain (split fastest) workgroup order
+            a.xcd_order = !(e && atoi(e) == 0);
+        }
+        const dim3 grid((unsigned)(p.S * a.n_ci * a.n_co));
+        FOSVOS_PROF("k_wgrad3x3_v2", st, flops);
+        hipLaunchKernelGGL(v2::k_wgrad3x3_v2, grid, dim3(v2::NT), v2::LDS_BYTES, st, a);
     } else if (!p.side) {
         using C = Cfg<2, 2>;
         if (device >= 0 && device < 64 && !once[device][0]) {

@@ -52,6 +52,9 @@ def main():
         dy = torch.randn(nb, H, W, cy, device=dev, generator=g).to(torch.bfloat16)
         if cy != co:
             dy[..., co:] = 0
+        if os.environ.get("BENCH_CONV_ZERO") == "1":  # DVFS check: the same instruction stream on all-zero operands
+            x.zero_()
+            dy.zero_()
         flop = 2.0 * nb * H * W * 9 * ci * co
         side = co == 16
         res = {}
