@@ -34,10 +34,13 @@ GRAD_REL_L2_EMU = 0.10
 # The 60-iteration fine-tune trajectory against the reference's (tests/golden/trajectory.npz): twelve optimizer steps, each
 # fed by gradients that carry the bf16 forward noise above, from weights that already differ a little - stated separately
 # from the single-step tolerances and measured on MI355X.
-TRAJ_IOU_TOL = 1e-3        # north_star: per-pixel mask IoU within 1e-3 of the reference
-TRAJ_LOGIT_TOL = 5e-2      # held-out logits after training, share of the logit range
-TRAJ_LOSS_RTOL = 5e-2
-TRAJ_DELTA_REL_L2 = 0.25
+# Measured (round 3): IoU(HIP-fine-tuned mask, reference-fine-tuned mask) 0.99943 - 1 of 15,360 pixels differs, inside the
+# logit band - both at IoU 0.877 against the annotation; held-out logits 0.84 % of their range; per-iteration losses within
+# 0.99 %; worst tensor's applied delta 5.2 % rel-L2.  The single-step tolerances hold for the whole trajectory.
+TRAJ_IOU_TOL = 1e-3             # north_star: per-pixel mask IoU within 1e-3 of the reference
+TRAJ_LOGIT_TOL = LOGIT_TOL      # held-out logits after training, share of the logit range
+TRAJ_LOSS_RTOL = 2e-2
+TRAJ_DELTA_REL_L2 = GRAD_REL_L2
 
 
 def make_net(seed, scheme="kaiming"):
