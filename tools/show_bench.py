@@ -11,9 +11,9 @@ for f in sys.argv[1:]:
     r = d.pop("roofline", None)
     print(f"{f}: {d['value']:.1f} {d['unit']}  {d['ms_per_step']:.4f} ms/step  n_gpus={d['n_gpus']} ranks={d.get('ranks')} "
           f"backend={d.get('backend')}")
-    for k in ("replicas", "infer", "cpu_baseline"):
+    for k in ("cold", "group1", "mixed_scales", "offline", "dp_strict", "replicas", "infer", "cpu_baseline"):
         if k in d:
-            print("  ", k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in d[k].items() if a not in ("protocol", "sample", "parallelism")})
+            print("  ", k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in d[k].items() if a not in ("protocol", "sample", "parallelism", "note", "workload")})
     if r:
         bk = r.pop("by_kernel")
         print("   roofline", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()
