@@ -3,24 +3,18 @@
 //
 //   dw[co][ci][ky][kx] = sum_{n,y,x} dy[n,y,x,co] * x[n,y+ky-1,x+kx-1,ci]        db[co] = sum dy[.,co]
 //
-// GEMM view: M = co, N = ci (x 9 taps), K = pixels: MFMA roofline.  v_mfma_f32_32x32x16_bf16, one k-step = 16
-// consecutive pixels of one image row.  Both operands are stored channel-contiguous (NHWC) while the contraction runs
-// over pixels, so both are transposed on the fly: a tile is staged in LDS as [32-channel half][pixel][64 B] and read with
-// ds_read_b64_tr_b16, which hands a lane the 4 pixels x 1 channel column of a 4 x 16 block.  A 32-lane half of a read
-// covers 4 pixels x 64 B = 256 contiguous bytes: conflict-free for every tap shift.
+// GEMM view: M = co, N = ci (x 9 taps), K = pixels: MFMA roofline.  Both operands are stored channel-contiguous (NHWC) while
+// the contraction runs over pixels, so both are transposed on the fly: a tile is staged in LDS pixel-major and read with
+// ds_read_b64_tr_b16, which hands a lane the 4 pixels x 1 channel column of a 4 x 16 block.
 //
-// Operand reuse is what this kernel is built around.  A tile is 8 rows x 16 pixels of dy and its 10 x 18 halo of x.  The
-// MFMA loop walks the HALO rows: the three x fragments of halo row R (kx = 0,1,2) meet the dy fragments of tile rows
-// R, R-1, R-2 (ky = 0,1,2), so every x fragment is read from LDS once and used three times, and a dy fragment stays in
-// registers for three halo rows: 76 transposed reads for 72 MFMAs per wave and tile (the 16x16x32 form of round 1 needed
-// 104 for 144, at twice the issue cost per FLOP).
+// Operand reuse is what the kernel is built around.  A tile is 8 rows x 16 pixels of dy and its 10 x 18 halo of x.  The MFMA
+// loop walks the HALO rows: the three x fragments of a halo row (kx = 0, 1, 2) meet the dy fragments of the tile rows one, two
+// and three above it in the walk (ky = 0, 1, 2), so every x fragment is read from LDS once and used three times, and a dy
+// fragment stays in registers for three rows.
 //
-// Workgroup = 4 waves in a WCO x WCI grid, wave (wc, wi) owns co 32wc..+31 x ci 32wi..+31 x 9 taps = nine 32x32
-// accumulators (144 VGPRs).  <2,2>: 64 co x 64 ci (the backbone layers); <1,4>: 32 x 128 (side_prep: 16 real output
-// channels in a 32-wide dy image).  The pixel range is split over blockIdx.x; each split writes one fp32 slab laid out
-// like dw itself ([co][ci][9], OIHW), so the reduction over splits is a plain elementwise sum in split order
-// (k_wgrad_reduce: bitwise reproducible, no float atomics, no transposes), queued per layer and run for many layers
-// in one launch.
+// The pixel range is split over workgroups; each split writes one fp32 slab laid out like dw itself ([co][ci][9], OIHW), so
+// the reduction over splits is a plain elementwise sum in split order (k_wgrad_fold / k_wgrad_reduce: bitwise reproducible,
+// no float atomics, no transposes), queued per layer and run for many layers in one launch.
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -31,350 +25,30 @@ namespace {
 constexpr int TH = 8;                    // tile rows
 constexpr int TPIX = TH * 16;            // 128 tile pixels
 constexpr int HALO_W = 18;
-constexpr int NPH = (TH + 2) * HALO_W;   // 180 halo pixels
 constexpr int BCI = 64;                  // ci granularity of the grid (and of the API contract)
 
 struct WgArgs {
     const uint16_t *x;   // [N,H,W,Ci]
     const uint16_t *dy;  // [N,H,W,Cy]  (Cy = roundup(Co,32))
     float *slabs;        // [S][Cor][Ci][9]
-    float *bias_part;    // [S * gridDim.y][Cor] column sums of dy per split and ci block (each sums its share of the tiles), or null
+    float *bias_part;    // [S * n_ci][Cor] column sums of dy per split and ci block (each sums its share of the tiles), or null
     int N, H, W, Ci, Cy, Cor;
     int tiles_x, tiles_y, n_tiles, tiles_per_split;
-#ifdef FOSVOS_WG_STAMP
-    unsigned long long *stamps;  // diagnostic build only (tools/wgrad_stamp_lab.hip): 8 sums per workgroup
-#endif
-    int lab;  // timing-only switches (FOSVOS_WGRAD_LAB; wrong results): 1 no slab store, 2 loads from the zero page
-    int S, n_ci, n_co, xcd_order;  // v2: 1-D grid of S * n_ci * n_co workgroups, decoded in the kernel (see there)
+    int lab;  // timing-only switch (FOSVOS_WGRAD_LAB; wrong results): 1 no slab store
+    int S, n_ci, n_co, xcd_order;  // 1-D grid of S * n_ci * n_co workgroups, decoded in the kernel (see there)
 };
 
 typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_ptr;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-// 8 bf16 of one channel: pixels p..p+3 (first read) and p+4..p+7 (second read, 4 x 64 B further)
-__device__ __forceinline__ bf16x8 tr_pair(const char *p) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 256));
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-}
-
-#ifdef FOSVOS_WG_STAMP
-unsigned long long *g_wg_stamps = nullptr;
-// wave 0 only: phase p's clocks are added to sum[p]; the stamp's own lgkmcnt(0) keeps s_memtime ordered with LDS reads
-#define FOSVOS_WG_STAMP_AT(p_)                                                                   \
-    {                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        unsigned long long now_;                                                                 \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");             \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        st_sum[p_] += now_ - st_last;                                                            \
-        st_last = now_;                                                                          \
-    }
-#else
-#define FOSVOS_WG_STAMP_AT(p_)
-#endif
-
-#ifndef FOSVOS_WG_LPR
-#define FOSVOS_WG_LPR 1
-#endif
-#ifndef FOSVOS_WG_BIAS_IN_ROWS
-#define FOSVOS_WG_BIAS_IN_ROWS 0
-#endif
-
-template <int WCO, int WCI>
-struct Cfg {
-    static constexpr int BCO = 32 * WCO, BCIW = 32 * WCI;   // workgroup tile
-    static constexpr int CHY = 4 * WCO, CHX = 4 * WCI;       // 16-byte pieces per pixel
-    // half stride = pixels x 64 B + 64: the two halves a staging store hits (8 lanes = one pixel's 128 B) then sit on
-    // different banks
-    static constexpr int Y_HALF = TPIX * 64 + 64, X_HALF = NPH * 64 + 64;
-    static constexpr int Y_BYTES = WCO * Y_HALF, X_BYTES = WCI * X_HALF, BUF_BYTES = Y_BYTES + X_BYTES;
-    static constexpr int NT = 64 * WCO * WCI;                       // threads: one wave per 32 x 32 output block
-    static constexpr int Y_IT = TPIX * CHY / NT;                   // staging pieces per thread
-    static constexpr int X_IT = (NPH * CHX + NT - 1) / NT;
-    static constexpr int LDS_BYTES = 2 * BUF_BYTES;                // two tile images (double buffer)
-    static_assert(WCO * WCI == 4 || WCO * WCI == 8, "4 or 8 waves per workgroup");
-    static_assert(TPIX * CHY % NT == 0, "dy pieces divide evenly");
-};
-
-template <int WCO, int WCI>
-__global__ __launch_bounds__(64 * WCO * WCI) __attribute__((amdgpu_waves_per_eu(WCO * WCI / 4, 2))) void k_wgrad3x3(const WgArgs a) {
-    using C = Cfg<WCO, WCI>;
-    extern __shared__ __attribute__((aligned(16))) char smem_w[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wc = wave / WCI, wi = wave % WCI;
-    const int split = blockIdx.x;
-    const int ci0 = blockIdx.y * C::BCIW;
-    const int co0 = blockIdx.z * C::BCO;
-    const int H = a.H, W = a.W;
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    // transposed-read address of this lane inside a half image: 16-lane group g reads channel block g&1 of the half,
-    // pixels 8(g>>1) + q (+4 for the second read); lane (q, p) of the group supplies row q, channels 4p..4p+3
-    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const int lane_off = ((g >> 1) * 8 + q) * 64 + (g & 1) * 32 + p * 8;
-    const int rd_y = wc * C::Y_HALF + lane_off;                 // + row * 16 * 64
-    const int rd_x = C::Y_BYTES + wi * C::X_HALF + lane_off;    // + (R * 18 + kx) * 64
-
-    // the bias gradient (column sums of dy) is the same for every ci block of a split: the ci blocks share it out by tile, so
-    // no workgroup carries all of it (all workgroups of a launch end together: the slowest sets the kernel time)
-    const bool do_bias = a.bias_part != nullptr;
-    float bsum[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
-
-    // ---- tile-independent staging plan of this thread: piece i = it * 256 + tid -> (pixel, 16-byte chunk)
-    // y_goff / x_goff: BYTE offsets inside the tile, from the tile's dy origin / from the x halo origin (one row and one
-    // pixel in front of the tile).  The loads are buffer loads: descriptor + this 32-bit offset + a scalar tile offset, and
-    // an out-of-image piece gets the offset ~0, which the descriptor's range check answers with zeros (no zero page, no
-    // 64-bit address arithmetic per piece)
-    unsigned y_goff[C::Y_IT], x_goff[C::X_IT];
-    int y_lds[C::Y_IT], y_rc[C::Y_IT];
-#pragma unroll
-    for (int it = 0; it < C::Y_IT; ++it) {
-        const int i = it * C::NT + tid, pix = i / C::CHY, c = i % C::CHY;
-        const int ty = pix >> 4, tx = pix & 15;
-        y_rc[it] = (ty << 16) | tx;
-        y_goff[it] = (unsigned)(((ty * W + tx) * a.Cy + co0 + c * 8) * 2);
-        y_lds[it] = (c >> 2) * C::Y_HALF + pix * 64 + (c & 3) * 16;
-    }
-    int x_lds[C::X_IT], x_rc[C::X_IT];
-#pragma unroll
-    for (int it = 0; it < C::X_IT; ++it) {
-        const int i = it * C::NT + tid, pix = i / C::CHX, c = i % C::CHX;
-        const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
-        x_rc[it] = pix < NPH ? ((hy << 16) | hx) : (0x7fff << 16);  // slots past the halo: never in the image, never stored
-        x_goff[it] = pix < NPH ? (unsigned)(((hy * W + hx) * a.Ci + ci0 + c * 8) * 2) : ~0u;  // slots past the halo: zeros
-        x_lds[it] = C::Y_BYTES + (c >> 2) * C::X_HALF + pix * 64 + (c & 3) * 16;
-    }
-    // x descriptor: based one row and one pixel in FRONT of the tensor, so that halo offsets are non-negative (the bytes in
-    // front of the tensor belong to out-of-image halo pieces, which are never requested)
-    const int64_t halo_shift = (int64_t)(W + 1) * a.Ci;
-    const unsigned y_total = (unsigned)((int64_t)a.N * H * W * a.Cy * 2), x_total = (unsigned)(((int64_t)a.N * H * W * a.Ci + halo_shift) * 2);
-    const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.dy), 0, y_total, 0x00020000);
-    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.x) - halo_shift, 0, x_total, 0x00020000);
-
-    const int t_begin = split * a.tiles_per_split;
-    const int t_end = min(t_begin + a.tiles_per_split, a.n_tiles);
-    int lt_x = t_begin % a.tiles_x, lt_y = (t_begin / a.tiles_x) % a.tiles_y, lt_n = t_begin / (a.tiles_x * a.tiles_y);
-
-    // Register-staged tile pipeline: tile t+1 is loaded into registers at the top of tile t (latency hidden by the MFMA
-    // loop) and written to the other LDS image behind it; one barrier per tile.
-    // The staging registers are NAMED scalars (macro-unrolled), not arrays: hipcc keeps the array form in scratch memory
-    // (store after load, reload before the LDS write), which serialises the pipeline.
-    static_assert(C::Y_IT <= 4 && C::X_IT <= 12, "staging register file");
-    uint4 py0, py1, py2, py3;
-    uint4 px0, px1, px2, px3, px4, px5, px6, px7, px8, px9, px10, px11;
-    py0 = py1 = py2 = py3 = px0 = px1 = px2 = px3 = px4 = px5 = px6 = px7 = px8 = px9 = px10 = px11 = make_uint4(0, 0, 0, 0);
-#define FOSVOS_WG_LDY(i_)                                                                               \
-    if constexpr ((i_) < C::Y_IT) {                                                                     \
-        unsigned v_ = y_goff[i_];                                                                       \
-        if (!interior_) v_ = ((y_rc[i_] >> 16) < vrows_ && (y_rc[i_] & 0xffff) < vcols_ && live_) ? v_ : ~0u; \
-        py##i_ = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, v_, ysoff_, 0)); \
-    }
-#define FOSVOS_WG_LDX(i_)                                                                               \
-    if constexpr ((i_) < C::X_IT) {                                                                     \
-        unsigned v_ = x_goff[i_];                                                                       \
-        if (!interior_) {                                                                               \
-            const int hy_ = x_rc[i_] >> 16, hx_ = x_rc[i_] & 0xffff;                                    \
-            v_ = (hy_ >= 1 - y0_ && hy_ <= vrows_ && hx_ >= 1 - x0_ && hx_ <= vcols_ && live_) ? v_ : ~0u; \
-        }                                                                                               \
-        px##i_ = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, v_, xsoff_, 0)); \
-    }
-    // tile-level scalars of the tile the NEXT loads fetch: (lt_x, lt_y, lt_n)
-#define FOSVOS_WG_TILE_SCALARS()                                                                        \
-    const int y0_ = lt_y * TH, x0_ = lt_x * 16;                                                         \
-    const int vrows_ = H - y0_, vcols_ = W - x0_;                                                       \
-    const int64_t org_ = ((int64_t)lt_n * H + y0_) * W + x0_;                                           \
-    const unsigned ysoff_ = (unsigned)(org_ * a.Cy * 2), xsoff_ = (unsigned)(org_ * a.Ci * 2);          \
-    /* interior: the whole halo lies inside the image and the loads are wanted - no per-piece checks */ \
-    const bool interior_ = y0_ >= 1 && y0_ + TH < H && x0_ >= 1 && x0_ + 16 < W && live_;
-#define FOSVOS_WG_ADVANCE()                                                                             \
-    if (++lt_x == a.tiles_x) {                                                                          \
-        lt_x = 0;                                                                                       \
-        if (++lt_y == a.tiles_y) { lt_y = 0; ++lt_n; }                                                  \
-    }
-    // piece p of the Y_IT + X_IT staging loads of a tile (dy pieces first)
-#define FOSVOS_WG_LDP(p_)                                                                               \
-    if constexpr ((p_) < C::Y_IT) { FOSVOS_WG_LDY_((p_)) }                                              \
-    else if constexpr ((p_) < C::Y_IT + C::X_IT) { FOSVOS_WG_LDX_((p_) - C::Y_IT) }
-#define FOSVOS_WG_LDY_(i_)                                                                              \
-    if constexpr ((i_) == 0) { FOSVOS_WG_LDY(0) } else if constexpr ((i_) == 1) { FOSVOS_WG_LDY(1) }    \
-    else if constexpr ((i_) == 2) { FOSVOS_WG_LDY(2) } else if constexpr ((i_) == 3) { FOSVOS_WG_LDY(3) }
-#define FOSVOS_WG_LDX_(i_)                                                                              \
-    if constexpr ((i_) == 0) { FOSVOS_WG_LDX(0) } else if constexpr ((i_) == 1) { FOSVOS_WG_LDX(1) }    \
-    else if constexpr ((i_) == 2) { FOSVOS_WG_LDX(2) } else if constexpr ((i_) == 3) { FOSVOS_WG_LDX(3) } \
-    else if constexpr ((i_) == 4) { FOSVOS_WG_LDX(4) } else if constexpr ((i_) == 5) { FOSVOS_WG_LDX(5) } \
-    else if constexpr ((i_) == 6) { FOSVOS_WG_LDX(6) } else if constexpr ((i_) == 7) { FOSVOS_WG_LDX(7) } \
-    else if constexpr ((i_) == 8) { FOSVOS_WG_LDX(8) } else if constexpr ((i_) == 9) { FOSVOS_WG_LDX(9) } \
-    else if constexpr ((i_) == 10) { FOSVOS_WG_LDX(10) } else if constexpr ((i_) == 11) { FOSVOS_WG_LDX(11) }
-#define FOSVOS_WG_LOAD_TILE()                                                                           \
-    {                                                                                                   \
-        FOSVOS_WG_TILE_SCALARS()                                                                        \
-        FOSVOS_WG_LDY(0) FOSVOS_WG_LDY(1) FOSVOS_WG_LDY(2) FOSVOS_WG_LDY(3) \
-        FOSVOS_WG_LDX(0) FOSVOS_WG_LDX(1) FOSVOS_WG_LDX(2) FOSVOS_WG_LDX(3) FOSVOS_WG_LDX(4) FOSVOS_WG_LDX(5) FOSVOS_WG_LDX(6) FOSVOS_WG_LDX(7) FOSVOS_WG_LDX(8) FOSVOS_WG_LDX(9) FOSVOS_WG_LDX(10) FOSVOS_WG_LDX(11) \
-        FOSVOS_WG_ADVANCE()                                                                             \
-    }
-#define FOSVOS_WG_STY(i_, img_) \
-    if constexpr ((i_) < C::Y_IT) *reinterpret_cast<uint4 *>((img_) + y_lds[i_]) = py##i_;
-#define FOSVOS_WG_STX(i_, img_)        \
-    if constexpr ((i_) < C::X_IT) {    \
-        if ((i_) * C::NT + tid < NPH * C::CHX) *reinterpret_cast<uint4 *>((img_) + x_lds[i_]) = px##i_; \
-    }
-#define FOSVOS_WG_STORE_TILE(img_) \
-    { FOSVOS_WG_STY(0, img_) FOSVOS_WG_STY(1, img_) FOSVOS_WG_STY(2, img_) FOSVOS_WG_STY(3, img_) FOSVOS_WG_STX(0, img_) FOSVOS_WG_STX(1, img_) FOSVOS_WG_STX(2, img_) FOSVOS_WG_STX(3, img_) FOSVOS_WG_STX(4, img_) FOSVOS_WG_STX(5, img_) FOSVOS_WG_STX(6, img_) FOSVOS_WG_STX(7, img_) FOSVOS_WG_STX(8, img_) FOSVOS_WG_STX(9, img_) FOSVOS_WG_STX(10, img_) FOSVOS_WG_STX(11, img_) }
-
-#ifdef FOSVOS_WG_STAMP
-    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
-#endif
-    if (t_begin < t_end) {
-        const bool live_ = !(a.lab & 2);
-        FOSVOS_WG_LOAD_TILE()
-        FOSVOS_WG_STORE_TILE(smem_w)
-    }
-    __syncthreads();
-    FOSVOS_WG_STAMP_AT(0)
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        char *cur = smem_w + ((tile - t_begin) & 1) * C::BUF_BYTES;
-        char *nxt = smem_w + (((tile - t_begin) & 1) ^ 1) * C::BUF_BYTES;
-        // The next tile's staging loads are NOT issued in one burst: a CU takes in ~17 B/clock from L2, so the 40 KB of a
-        // tile need as long as its 72 MFMAs per wave, and a wave that issues all of them up front sits in the load
-        // instructions (the memory pipe accepts them only as data returns) instead of starting its matrix work - measured
-        // with tools/wgrad_stamp_lab.hip: 2270 clocks per tile in the issue block.  One or two pieces ride in every
-        // halo row of the MFMA loop instead.  Without a next tile the pieces read the zero page (never stored).
-        const bool has_next = tile + 1 < t_end;
-        const bool live_ = has_next && !(a.lab & 2);
-        FOSVOS_WG_TILE_SCALARS()
-        FOSVOS_WG_STAMP_AT(1)
-        if (!FOSVOS_WG_BIAS_IN_ROWS && do_bias && (tile % (int)gridDim.y) == (int)blockIdx.y) {  // thread t keeps chunk t % CHY
-#pragma unroll
-            for (int k = 0; k < C::Y_IT; ++k) {
-                float f[8];
-                unpack8(*reinterpret_cast<const uint4 *>(cur + y_lds[k]), f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bsum[e] += f[e];
-            }
-        }
-        FOSVOS_WG_STAMP_AT(2)
-        // ---- MFMA loop over the 10 halo rows: x fragments of row R meet dy rows R (ky 0), R-1 (ky 1), R-2 (ky 2).
-        // The transposed reads of row R+1 are placed in front of the MFMAs of row R (a compiler memory fence per row keeps
-        // them - and the row's staging loads - in their row), so a read has a row of matrix work to land.
-        const char *yb = cur + rd_y, *xb = cur + rd_x;
-        bf16x8 a0, a1, a2, an, b0, b1, b2, bn0, bn1, bn2;
-        a1 = a2 = an = bf16x8{};
-        bn0 = bn1 = bn2 = bf16x8{};
-        a0 = tr_pair(yb);
-        b0 = tr_pair(xb + 0 * 64);
-        b1 = tr_pair(xb + 1 * 64);
-        b2 = tr_pair(xb + 2 * 64);
-        constexpr int NP = C::Y_IT + C::X_IT;  // staging pieces per tile, dealt over the TH + 2 rows
-#define FOSVOS_WG_ROW(R)                                                                                \
-        {                                                                                                   \
-            /* FOSVOS_WG_LPR staging pieces per row from the first row on */                                 \
-            FOSVOS_WG_LDP(FOSVOS_WG_LPR * (R))                                                              \
-            if constexpr (FOSVOS_WG_LPR > 1) { FOSVOS_WG_LDP(FOSVOS_WG_LPR * (R) + 1) }                     \
-            if constexpr (NP > (TH + 2) && FOSVOS_WG_LPR == 1) { FOSVOS_WG_LDP((TH + 2) + (R)) }            \
-            /* bias: column sums of the dy tile, one 16-byte piece per row (thread t keeps chunk t % CHY) */ \
-            if constexpr (FOSVOS_WG_BIAS_IN_ROWS && (R) < C::Y_IT) {                                        \
-                if (do_bias) {                                                                              \
-                    float f_[8];                                                                            \
-                    unpack8(*reinterpret_cast<const uint4 *>(cur + y_lds[R]), f_);                          \
-                    _Pragma("unroll") for (int e = 0; e < 8; ++e) bsum[e] += f_[e];                         \
-                }                                                                                           \
-            }                                                                                               \
-            if constexpr ((R) + 1 < TH + 2) {                                                               \
-                bn0 = tr_pair(xb + (((R) + 1) * HALO_W + 0) * 64);                                          \
-                bn1 = tr_pair(xb + (((R) + 1) * HALO_W + 1) * 64);                                          \
-                bn2 = tr_pair(xb + (((R) + 1) * HALO_W + 2) * 64);                                          \
-                if constexpr ((R) + 1 < TH) an = tr_pair(yb + ((R) + 1) * 16 * 64);                         \
-            }                                                                                               \
-            {                                                                                               \
-                if constexpr ((R) < TH) {                                                                   \
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0], 0, 0, 0);              \
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[1], 0, 0, 0);              \
-                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[2], 0, 0, 0);              \
-                }                                                                                           \
-                if constexpr ((R) >= 1 && (R) <= TH) {                                                      \
-                    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[3], 0, 0, 0);              \
-                    acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[4], 0, 0, 0);              \
-                    acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[5], 0, 0, 0);              \
-                }                                                                                           \
-                if constexpr ((R) >= 2) {                                                                   \
-                    acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[6], 0, 0, 0);              \
-                    acc[7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[7], 0, 0, 0);              \
-                    acc[8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[8], 0, 0, 0);              \
-                }                                                                                           \
-            }                                                                                               \
-            asm volatile("" ::: "memory");                                                                  \
-            a2 = a1; a1 = a0; a0 = an; b0 = bn0; b1 = bn1; b2 = bn2;                                        \
-        }
-        static_assert(TH + 2 == 10 && NP <= 2 * (TH + 2), "row macro instances / pieces per row");
-        FOSVOS_WG_ROW(0) FOSVOS_WG_ROW(1) FOSVOS_WG_ROW(2) FOSVOS_WG_ROW(3) FOSVOS_WG_ROW(4)
-        FOSVOS_WG_ROW(5) FOSVOS_WG_ROW(6) FOSVOS_WG_ROW(7) FOSVOS_WG_ROW(8) FOSVOS_WG_ROW(9)
-        if (has_next) FOSVOS_WG_ADVANCE()
-        FOSVOS_WG_STAMP_AT(3)
-        // image `nxt` was last read during tile-1 (every wave has passed that tile's barrier)
-        if (has_next) FOSVOS_WG_STORE_TILE(nxt)
-        FOSVOS_WG_STAMP_AT(4)
-        __syncthreads();  // tile+1 is in place and image `cur` is retired
-        FOSVOS_WG_STAMP_AT(5)
-    }
-    if (do_bias) {
-        // 256 x 8 partials -> BCO channel sums in a fixed order: channel ch = 8 c + e lives in the threads t = c (mod CHY)
-        float *sb = reinterpret_cast<float *>(smem_w);  // [NT][9] floats
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sb[tid * 9 + e] = bsum[e];
-        __syncthreads();
-        if (tid < C::BCO && co0 + tid < a.Cor) {
-            const int c = tid >> 3, e = tid & 7;
-            float acc_b = 0.f;
-            for (int t2 = c; t2 < C::NT; t2 += C::CHY) acc_b += sb[t2 * 9 + e];
-            a.bias_part[((int64_t)split * gridDim.y + blockIdx.y) * a.Cor + co0 + tid] = acc_b;
-        }
-    }
-    // ---- slab write, laid out like dw (OIHW): accumulator register r of lane l is
-    //   co = co0 + 32 wc + (r&3) + 8 (r>>2) + 4 (l>>5),  ci = ci0 + 32 wi + (l&31),  9 taps contiguous (36 B);
-    // a wave instruction covers 32 consecutive ci of one co row
-    float *slab = a.slabs + (int64_t)split * a.Cor * a.Ci * 9;
-    const int ci = ci0 + wi * 32 + (lane & 31);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (co >= a.Cor || (a.lab & 1)) continue;  // side_prep: rows 16..31 of the fragment are padding (registers 8..15)
-        float *d = slab + ((int64_t)co * a.Ci + ci) * 9;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) d[t] = acc[t][r];
-    }
-#ifdef FOSVOS_WG_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    FOSVOS_WG_STAMP_AT(6)
-    if (a.stamps && tid == 0) {
-        unsigned long long *o = a.stamps + (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
-        for (int i = 0; i < 8; ++i) o[i] = st_sum[i];
-    }
-#endif
-}
 
 // =====================================================================================================================
-// Round 3 form of the MFMA kernel for the backbone layers (Co % 64 == 0): same tile (8 x 16 pixels of dy, 10 x 18 halo of
-// x), same grid, same slabs - rebuilt around three measurements of the form above (1 wave per SIMD, 280 registers, 33-35 % of
-// the MFMA cycles when alone on the chip, 25 % of its wave cycles in s_waitcnt / s_barrier):
+// The MFMA kernel (round 3; round 2's ran one 280-register wave per SIMD with register-staged tiles: 33-35 % of the MFMA
+// cycles when alone on the chip, 25 % of its wave cycles in s_waitcnt / s_barrier, 2x its algorithmic bytes from beyond L2):
 //   * staging is LDS-DMA (buffer_load ... lds): the next tile goes from L2 straight into the other LDS image while the
 //     MFMA loop runs - no staging registers (-40), no ds_write, nothing to wait for behind the loop but the DMA itself;
 //     pieces are 8 pixels x 128 B, i.e. whole 128-byte lines of the NHWC tensors;
 //   * 8 waves per workgroup, two per SIMD, each 32 co x 16 ci x 9 taps on v_mfma_f32_16x16x32_bf16 (18 accumulators of 4
 //     registers): ~150 registers per wave, so one of these workgroups and one 192-register igemm workgroup still share a CU;
-//   * the bias gradient (column sums of dy) is one extra MFMA against a vector of ones, taken in turn by the waves.
+//   * the bias gradient (column sums of dy) is four v_dot2c_f32_bf16 per dy fragment, taken in turn by the waves.
 // LDS image of a tile: [pixel][128 B = 64 channels], 16-byte chunk c of pixel px stored at chunk slot c ^ 2((px >> 1) & 3).
 // An LDS-DMA instruction writes lane i's 16 bytes at base + 16 i, so the swizzle is applied to the SOURCE address; the
 // transposed reads apply the same XOR.  Row strides (16 px for dy, 24 px for the x halo: 18 used) are multiples of 8 px, so
@@ -383,25 +57,35 @@ __global__ __launch_bounds__(64 * WCO * WCI) __attribute__((amdgpu_waves_per_eu(
 // k index of an MFMA (32 pixels): lane group g, element j  <->  tile row r + 4 (g >> 1), pixel 4 (g & 1) + (j & 3) + 8 (j >> 2):
 // any bijection does as long as both operands use the same one - this one makes the halves of a read contiguous.
 // The loop walks R = 0..5: the x fragments of halo rows (R, R + 4) meet the dy fragments of tile rows (R - ky, R + 4 - ky).
-#ifndef FOSVOS_W2_PPR
-#define FOSVOS_W2_PPR 2  // staging pieces per row of the MFMA loop (lab: 3 = all six in the first two rows)
-#endif
+// SIDE = true is the side_prep form (16 output channels in a 32-wide dy image, 64-byte pixel rows): four waves, each
+// 16 co x 16 ci x 9 taps, 64 ci per workgroup; everything else - tile, images, walk, slabs - is the same code.
 namespace v2 {
 constexpr int XROW = 24;                          // pixels per halo row in LDS (18 used)
-constexpr int Y_BYTES = TPIX * 128;               // 16 KB
 constexpr int X_BYTES = (TH + 2) * XROW * 128;    // 30 KB
-constexpr int BUF_BYTES = Y_BYTES + X_BYTES;
-constexpr int LDS_BYTES = 2 * BUF_BYTES;          // 92 KB: two tile images
-constexpr int NT = 512;
-constexpr int Y_PIECES = TPIX / 8, X_PIECES = (TH + 2) * XROW / 8;   // 16 + 30 pieces of 1 KB per tile
-constexpr int N_IT = (Y_PIECES + X_PIECES + 7) / 8;                   // pieces per wave (6; waves 6, 7 issue 5)
-static_assert(Y_PIECES == 16 && X_PIECES == 30 && N_IT == 6, "piece schedule below");
+constexpr int X_PIECES = (TH + 2) * XROW / 8;     // 30 pieces of 8 pixels x 128 B
+
+template <bool SIDE>
+struct Cfg2 {
+    static constexpr int NW = SIDE ? 4 : 8;                 // waves per workgroup
+    static constexpr int NT = 64 * NW;
+    static constexpr int NU = SIDE ? 1 : 2;                 // 16-channel dy sub-blocks per wave
+    static constexpr int BCO = SIDE ? 16 : 64;              // output channels per workgroup
+    static constexpr int YPX = SIDE ? 64 : 128;             // bytes of a dy pixel row in LDS
+    static constexpr int Y_BYTES = TPIX * YPX;              // 8 / 16 KB
+    static constexpr int BUF_BYTES = Y_BYTES + X_BYTES;
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;         // 76 / 92 KB: two tile images
+    static constexpr int Y_PIECES = Y_BYTES / 1024;         // 8 (16 px x 64 B) / 16 (8 px x 128 B)
+    static constexpr int NXIT = (X_PIECES + NW - 1) / NW;   // x pieces per wave: 8 / 4
+    static constexpr int N_IT = 2 + NXIT;                   // pieces per wave and tile: two of dy, then x
+    static_assert(Y_PIECES == 2 * NW, "two dy pieces per wave, four tile rows apart");
+};
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-__device__ __forceinline__ bf16x8 tr_pair16(const char *p) {  // 8 pixels of one channel: p .. +3, then 8 pixels on (+1024 B)
+// 8 pixels of one channel: p .. +3 and the 4 pixels 8 further along the row (`second` bytes on)
+__device__ __forceinline__ bf16x8 tr_pair16(const char *p, int second) {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 1024));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + second));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
@@ -419,59 +103,70 @@ __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigne
 }
 #pragma clang diagnostic pop
 
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wgrad3x3_v2(const WgArgs a) {
+template <bool SIDE>
+__global__ __launch_bounds__(Cfg2<SIDE>::NT) __attribute__((amdgpu_waves_per_eu(SIDE ? 2 : 3, SIDE ? 4 : 3))) void k_wgrad3x3_v2(const WgArgs a) {
+    using C = Cfg2<SIDE>;
+    constexpr int NW = C::NW, NU = C::NU, YPX = C::YPX, Y_BYTES = C::Y_BYTES, BUF_BYTES = C::BUF_BYTES, N_IT = C::N_IT;
     extern __shared__ __attribute__((aligned(16))) char smem_w[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wc = wave >> 2, wi = wave & 3;          // 32-co block, 16-ci block of this wave
+    const int wc = SIDE ? 0 : wave >> 2, wi = wave & 3;  // 32-co block (backbone), 16-ci block of this wave
     // Workgroup -> (pixel split, ci block, co block).  The n_ci * n_co workgroups of a split walk the same tiles: each x slice
     // is read by n_co of them, each dy slice by n_ci.  The dispatcher deals consecutive workgroup ids round-robin over the 8
     // XCDs (each with its own L2), so with a plain 3-D grid the workgroups that share operands never meet in an L2 and every
-    // slice is fetched from beyond L2 once per reader (measured: the kernel moved 2x its algorithmic bytes and did not get
-    // faster when its staging stalls were removed).  Remapped - a speed choice, never correctness: the ids that share an XCD
-    // (id % 8) take one contiguous eighth of the (split, ci, co) space, co fastest, and start together.
+    // slice is fetched from beyond L2 once per reader (measured: 347 MB per launch instead of 203).  Remapped - a speed choice,
+    // never correctness: the ids that share an XCD (id % 8) take one contiguous eighth of the (split, ci, co) space, co
+    // fastest, and start together.
     int bid = blockIdx.x;
     if (a.xcd_order) {
         const int n_wg = gridDim.x, q8 = n_wg >> 3, r8 = n_wg & 7, xcd = bid & 7;
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);  // bijective for any n_wg
     }
     const int co_blk = bid % a.n_co, ci_blk = (bid / a.n_co) % a.n_ci, split = bid / (a.n_co * a.n_ci);
-    const int ci0 = ci_blk * 64, co0 = co_blk * 64;
+    const int ci0 = ci_blk * 64, co0 = co_blk * C::BCO;
     const int H = a.H, W = a.W;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)smem_w);
 
-    f32x4 acc[9][2];
+    f32x4 acc[9][NU];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum[2] = {0.f, 0.f};  // bias gradient: this lane's share (its 8 pixels of a k-step) of sum over pixels of dy[., co]
+        for (int u = 0; u < NU; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[NU];  // bias gradient: this lane's share (its 8 pixels of a k-step) of sum over pixels of dy[., co]
+#pragma unroll
+    for (int u = 0; u < NU; ++u) bsum[u] = 0.f;
 
-    // ---- transposed-read addresses of this lane (bytes inside a tile image)
+    // ---- transposed-read addresses of this lane (bytes inside a tile image).  The chunk swizzle of a 128-byte pixel row
+    // (8 chunks) is c ^ 2((px >> 1) & 3); of a 64-byte row (4 chunks: the side form's dy) c ^ 2((px >> 2) & 1): either way a
+    // 32-lane half of a read - 8 consecutive pixels x 32 B - lands on 64 distinct banks
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const int pxl = 4 * (g & 1) + q;                                   // pixel inside the row, first read
-    auto swz = [](int px, int c) { return (c ^ (2 * ((px >> 1) & 3))) * 16; };
-    int rd_y[2], rd_x[3];
+    auto swz128 = [](int px, int c) { return (c ^ (2 * ((px >> 1) & 3))) * 16; };
+    auto swz64 = [](int px, int c) { return (c ^ (2 * ((px >> 2) & 1))) * 16; };
+    int rd_y[NU], rd_x[3];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-        rd_y[u] = ((4 * (g >> 1)) * 16 + pxl) * 128 + swz(pxl, 2 * (2 * wc + u) + (p >> 1)) + (p & 1) * 8;
+    for (int u = 0; u < NU; ++u)
+        rd_y[u] = ((4 * (g >> 1)) * 16 + pxl) * YPX + (SIDE ? swz64(pxl, p >> 1) : swz128(pxl, 2 * (2 * wc + u) + (p >> 1))) + (p & 1) * 8;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
-        rd_x[kx] = Y_BYTES + ((4 * (g >> 1)) * XROW + pxl + kx) * 128 + swz(pxl + kx, 2 * wi + (p >> 1)) + (p & 1) * 8;
+        rd_x[kx] = Y_BYTES + ((4 * (g >> 1)) * XROW + pxl + kx) * 128 + swz128(pxl + kx, 2 * wi + (p >> 1)) + (p & 1) * 8;
 
-    // ---- staging plan: piece pc = 8 it + wave; pieces 0..15 are dy, 16..45 x.  Lane i fetches the 16 bytes that belong at
-    // LDS offset 1024 pc' + 16 i: pixel 8 pc' + (i >> 3), chunk slot i & 7 -> source chunk (i & 7) ^ swizzle(pixel).
-    // The two dy pieces of a wave are 4 tile rows apart (same columns): one offset register serves both.
-    const int ppx = lane >> 3, slot = lane & 7;
-    unsigned goff_y, goff_x[N_IT - 2];
+    // ---- staging plan.  Piece pc of a tile image is its pc-th kilobyte: lane i fetches the 16 bytes that belong at LDS
+    // offset 1024 pc + 16 i, i.e. the source chunk (slot ^ swizzle) of its pixel.  dy: pieces it * NW + wave, it = 0, 1 - the
+    // two are four tile rows apart (same columns), so one offset register serves both.  x: pieces (it - 2) * NW + wave.
+    const int ypx = SIDE ? lane >> 2 : lane >> 3, yslot = SIDE ? lane & 3 : lane & 7;  // pixel / chunk slot inside a dy piece
+    const int ppx = lane >> 3, slot = lane & 7;                                         // ... inside an x piece
+    constexpr int YPP = SIDE ? 16 : 8;                                                  // pixels per dy piece
+    unsigned goff_y, goff_x[C::NXIT];
     {
-        const int pix = wave * 8 + ppx, ty = pix >> 4, tx = pix & 15;
-        goff_y = (unsigned)(((ty * W + tx) * a.Cy + co0 + (slot ^ (2 * ((tx >> 1) & 3))) * 8) * 2);
+        const int pix = wave * YPP + ypx, ty = pix >> 4, tx = pix & 15;
+        const int c = SIDE ? yslot ^ (2 * ((tx >> 2) & 1)) : yslot ^ (2 * ((tx >> 1) & 3));
+        goff_y = (unsigned)(((ty * W + tx) * a.Cy + co0 + c * 8) * 2);
     }
 #pragma unroll
     for (int it = 2; it < N_IT; ++it) {
-        const int pix = ((it - 2) * 8 + wave) * 8 + ppx, hy = pix / XROW, hx = pix - hy * XROW;
-        const bool used = (it - 2) * 8 + wave < X_PIECES && hx < HALO_W;
+        const int pix = ((it - 2) * NW + wave) * 8 + ppx, hy = pix / XROW, hx = pix - hy * XROW;
+        const bool used = (it - 2) * NW + wave < X_PIECES && hx < HALO_W;
         goff_x[it - 2] = used ? (unsigned)(((hy * W + hx) * a.Ci + ci0 + (slot ^ (2 * ((hx >> 1) & 3))) * 8) * 2) : ~0u;
     }
     const unsigned y_step = (unsigned)(4 * W * a.Cy * 2);  // dy piece it = 1: four tile rows further
@@ -490,19 +185,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     {                                                                                                           \
         unsigned v_ = goff_y + (it_) * y_step;                                                                  \
         if (!interior_) {                                                                                       \
-            const int pix_ = ((it_) * 8 + wave) * 8 + ppx;                                                      \
+            const int pix_ = ((it_) * NW + wave) * YPP + ypx;                                                   \
             v_ = ((pix_ >> 4) < vrows_ && (pix_ & 15) < vcols_) ? v_ : ~0u;                                     \
         }                                                                                                       \
-        dma16(y_rsrc, (img_) + ((it_) * 8 + wave) * 1024, v_, ysoff_);                                          \
+        dma16(y_rsrc, (img_) + ((it_) * NW + wave) * 1024, v_, ysoff_);                                         \
     }
 #define FOSVOS_W2_PIECE_X(it_, img_)                                                                            \
-    if ((it_) < N_IT - 1 || wave < 6) {                                                                         \
+    if (((it_) - 1) * NW <= X_PIECES || ((it_) - 2) * NW + wave < X_PIECES) {                                   \
         unsigned v_ = goff_x[(it_) - 2];                                                                        \
         if (!interior_) {                                                                                       \
-            const int pix_ = (((it_) - 2) * 8 + wave) * 8 + ppx, hy_ = pix_ / XROW, hx_ = pix_ - hy_ * XROW;    \
+            const int pix_ = (((it_) - 2) * NW + wave) * 8 + ppx, hy_ = pix_ / XROW, hx_ = pix_ - hy_ * XROW;   \
             v_ = (hy_ >= 1 - y0_ && hy_ <= vrows_ && hx_ >= 1 - x0_ && hx_ <= vcols_) ? v_ : ~0u;               \
         }                                                                                                       \
-        dma16(x_rsrc, (img_) + Y_BYTES + (((it_) - 2) * 8 + wave) * 1024, v_, xsoff_);                          \
+        dma16(x_rsrc, (img_) + Y_BYTES + (((it_) - 2) * NW + wave) * 1024, v_, xsoff_);                         \
     }
 #define FOSVOS_W2_TILE_SCALARS()                                                                                \
     const int y0_ = lt_y * TH, x0_ = lt_x * 16;                                                                 \
@@ -515,18 +210,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         lt_x = 0;                                                                                               \
         if (++lt_y == a.tiles_y) { lt_y = 0; ++lt_n; }                                                          \
     }
+    // piece `it_` (of the tile the scalars in scope describe), if this form has that many
+#define FOSVOS_W2_PIECE_ANY(it_, img_)                                                                          \
+    if constexpr ((it_) < 2) { FOSVOS_W2_PIECE_Y(it_, img_) }                                                   \
+    else if constexpr ((it_) < N_IT) { FOSVOS_W2_PIECE_X(it_, img_) }
 #define FOSVOS_W2_STAGE(img_)                                                                                   \
     {                                                                                                           \
         FOSVOS_W2_TILE_SCALARS()                                                                                \
-        FOSVOS_W2_PIECE_Y(0, img_) FOSVOS_W2_PIECE_Y(1, img_)                                                   \
-        FOSVOS_W2_PIECE_X(2, img_) FOSVOS_W2_PIECE_X(3, img_) FOSVOS_W2_PIECE_X(4, img_) FOSVOS_W2_PIECE_X(5, img_) \
+        FOSVOS_W2_PIECE_ANY(0, img_) FOSVOS_W2_PIECE_ANY(1, img_) FOSVOS_W2_PIECE_ANY(2, img_)                  \
+        FOSVOS_W2_PIECE_ANY(3, img_) FOSVOS_W2_PIECE_ANY(4, img_) FOSVOS_W2_PIECE_ANY(5, img_)                  \
+        FOSVOS_W2_PIECE_ANY(6, img_) FOSVOS_W2_PIECE_ANY(7, img_) FOSVOS_W2_PIECE_ANY(8, img_)                  \
+        FOSVOS_W2_PIECE_ANY(9, img_)                                                                            \
         FOSVOS_W2_ADVANCE()                                                                                     \
     }
-    // piece `it_` of the next tile, issued from inside the MFMA loop (one per row: see there)
-#define FOSVOS_W2_PIECE(it_, img_)                                                                              \
-    if (has_next) {                                                                                             \
-        if constexpr ((it_) < 2) { FOSVOS_W2_PIECE_Y(it_, img_) } else { FOSVOS_W2_PIECE_X(it_, img_) }         \
-    }
+    static_assert(N_IT <= 10, "piece macros cover ten pieces per wave");
+    // two pieces of the NEXT tile, issued from inside the MFMA loop in front of row R (see there)
+#define FOSVOS_W2_PIECES_OF_ROW(R, img_)                                                                        \
+    if (has_next) { FOSVOS_W2_PIECE_ANY(2 * (R), img_) FOSVOS_W2_PIECE_ANY(2 * (R) + 1, img_) }
 
     if (t_begin < t_end) FOSVOS_W2_STAGE(lds0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA has landed ...
@@ -548,60 +248,62 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         const int par = (tile - t_begin) & 1;
         const char *cur = smem_w + par * BUF_BYTES;
         // The other image was last read during tile - 1 and every wave has passed that tile's barrier, so the next tile's DMA
-        // may start now.  Its six pieces are NOT issued in one burst: an LDS-DMA instruction holds its wave for ~60-180
-        // clocks while the memory pipe takes it in, and eight waves bursting together left the matrix pipe idle for the
-        // first ~1000 clocks of every tile.  Two pieces ride in front of each of the first three rows; the last ones then
-        // have the other three rows of matrix work (half the tile) to land under before the wave waits for them.
+        // may start now.  Its pieces are NOT issued in one burst: an LDS-DMA instruction holds its wave for ~60-180 clocks
+        // while the memory pipe takes it in, and all waves bursting together left the matrix pipe idle for the first ~1000
+        // clocks of every tile.  Two pieces ride in front of each of the first rows (three rows for the backbone form's six);
+        // the last ones then have the remaining rows of matrix work to land under before the wave waits for them (one piece
+        // per row, the last issued in the last row, was 8 % slower: measured).
         const bool has_next = tile + 1 < t_end;
         const unsigned nxt_ = lds0 + (par ^ 1) * BUF_BYTES;
         FOSVOS_W2_TILE_SCALARS()
         // the bias sums of a tile are taken by one ci block of the grid and, inside it, by one of the four ci waves in turn
         const bool my_bias = do_bias && (tile % a.n_ci) == ci_blk && ((tile / a.n_ci) & 3) == wi;
 
-        const char *yb0 = cur + rd_y[0], *yb1 = cur + rd_y[1];
+        const char *yb[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) yb[u] = cur + rd_y[u];
         const char *xb0 = cur + rd_x[0], *xb1 = cur + rd_x[1], *xb2 = cur + rd_x[2];
-        bf16x8 a0[2], a1[2], a2[2], b[3], bn[3];
-        a0[0] = a0[1] = a1[0] = a1[1] = a2[0] = a2[1] = bn[0] = bn[1] = bn[2] = bf16x8{};
-        b[0] = tr_pair16(xb0);
-        b[1] = tr_pair16(xb1);
-        b[2] = tr_pair16(xb2);
-        // Row R: the dy fragments of row R are requested in front of the row's MFMAs and used by its LAST six (ky = 0); the x
-        // fragments of row R + 1 are requested behind the first six (ky = 2), whose dy registers they may then take, and have
-        // the other twelve to land under: every request has matrix work of this very wave to cover it (the two waves of a SIMD run in lockstep - same program, one
-        // barrier per tile - and do not cover each other's LDS latency).  A compiler fence per row keeps the reads in their row.
+        bf16x8 a0[NU], a1[NU], a2[NU], b[3], bn[3];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) a0[u] = a1[u] = a2[u] = bf16x8{};
+        bn[0] = bn[1] = bn[2] = bf16x8{};
+        b[0] = tr_pair16(xb0, 1024);
+        b[1] = tr_pair16(xb1, 1024);
+        b[2] = tr_pair16(xb2, 1024);
+        // Row R: the dy fragments of row R are requested in front of the row's MFMAs and used by its LAST ones (ky = 0); the x
+        // fragments of row R + 1 are requested behind the first ones (ky = 2), whose dy registers they may then take, and have
+        // the others to land under: every request has matrix work of this very wave to cover it (the waves of a SIMD run in
+        // lockstep - same program, one barrier per tile - and do not cover each other's LDS latency).  A compiler fence per
+        // row keeps the reads in their row.
 #define FOSVOS_W2_ROW(R)                                                                                        \
         {                                                                                                           \
-            a2[0] = a1[0]; a2[1] = a1[1]; a1[0] = a0[0]; a1[1] = a0[1];                                             \
-            if constexpr (FOSVOS_W2_PPR == 2 && (R) < 3) { FOSVOS_W2_PIECE(2 * (R), nxt_) FOSVOS_W2_PIECE(2 * (R) + 1, nxt_) } \
-            if constexpr (FOSVOS_W2_PPR == 3 && (R) < 2) {                                                          \
-                FOSVOS_W2_PIECE(3 * (R), nxt_) FOSVOS_W2_PIECE(3 * (R) + 1, nxt_) FOSVOS_W2_PIECE(3 * (R) + 2, nxt_) } \
+            _Pragma("unroll") for (int u = 0; u < NU; ++u) { a2[u] = a1[u]; a1[u] = a0[u]; }                        \
+            FOSVOS_W2_PIECES_OF_ROW(R, nxt_)                                                                        \
             if constexpr ((R) < 4) {                                                                                \
-                a0[0] = tr_pair16(yb0 + (R) * 16 * 128);                                                            \
-                a0[1] = tr_pair16(yb1 + (R) * 16 * 128);                                                            \
+                _Pragma("unroll") for (int u = 0; u < NU; ++u) a0[u] = tr_pair16(yb[u] + (R) * 16 * YPX, 8 * YPX);  \
             }                                                                                                       \
             if constexpr ((R) >= 2) {                                                                               \
                 _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                    \
-                _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                       \
+                _Pragma("unroll") for (int u = 0; u < NU; ++u)                                                      \
                     acc[6 + kx][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[u], b[kx], acc[6 + kx][u], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);  /* the registers of a2 are free from here: the next reads may take them */ \
             }                                                                                                       \
             if constexpr ((R) + 1 < 6) {                                                                            \
-                bn[0] = tr_pair16(xb0 + ((R) + 1) * XROW * 128);                                                    \
-                bn[1] = tr_pair16(xb1 + ((R) + 1) * XROW * 128);                                                    \
-                bn[2] = tr_pair16(xb2 + ((R) + 1) * XROW * 128);                                                    \
+                bn[0] = tr_pair16(xb0 + ((R) + 1) * XROW * 128, 1024);                                              \
+                bn[1] = tr_pair16(xb1 + ((R) + 1) * XROW * 128, 1024);                                              \
+                bn[2] = tr_pair16(xb2 + ((R) + 1) * XROW * 128, 1024);                                              \
             }                                                                                                       \
             if constexpr ((R) >= 1 && (R) <= 4) {                                                                   \
                 _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                    \
-                _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                       \
+                _Pragma("unroll") for (int u = 0; u < NU; ++u)                                                      \
                     acc[3 + kx][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u], b[kx], acc[3 + kx][u], 0, 0, 0); \
             }                                                                                                       \
             if constexpr ((R) < 4) {                                                                                \
                 _Pragma("unroll") for (int kx = 0; kx < 3; ++kx)                                                    \
-                _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                       \
+                _Pragma("unroll") for (int u = 0; u < NU; ++u)                                                      \
                     acc[kx][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[u], b[kx], acc[kx][u], 0, 0, 0);        \
                 if (my_bias) {                                                                                      \
-                    bsum[0] = add8(a0[0], bsum[0]);                                                                 \
-                    bsum[1] = add8(a0[1], bsum[1]);                                                                 \
+                    _Pragma("unroll") for (int u = 0; u < NU; ++u) bsum[u] = add8(a0[u], bsum[u]);                  \
                 }                                                                                                   \
             }                                                                                                       \
             asm volatile("" ::: "memory");                                                                          \
@@ -616,14 +318,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     // ---- bias partials: lane (g, i) of wave (wc, wi) holds, for channel 32 wc + 16 u + i, the sum over its quarter of the
     // k index (group g) of the tiles that wave took: 16 partials per channel, added in a fixed order
     if (do_bias) {
-        float *sb = reinterpret_cast<float *>(smem_w);  // [4 wi][4 g][64 co]
+        float *sb = reinterpret_cast<float *>(smem_w);  // [4 wi][4 g][BCO]
 #pragma unroll
-        for (int u = 0; u < 2; ++u) sb[(wi * 4 + g) * 64 + wc * 32 + u * 16 + (lane & 15)] = bsum[u];
+        for (int u = 0; u < NU; ++u) sb[(wi * 4 + g) * C::BCO + wc * 32 + u * 16 + (lane & 15)] = bsum[u];
         __syncthreads();
-        if (tid < 64 && co0 + tid < a.Cor) {
+        if (tid < C::BCO && co0 + tid < a.Cor) {
             float acc_b = 0.f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) acc_b += sb[k * 64 + tid];
+            for (int k = 0; k < 16; ++k) acc_b += sb[k * C::BCO + tid];
             a.bias_part[((int64_t)split * a.n_ci + ci_blk) * a.Cor + co0 + tid] = acc_b;
         }
     }
@@ -632,7 +334,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     float *slab = a.slabs + (int64_t)split * a.Cor * a.Ci * 9;
     const int ci = ci0 + wi * 16 + (lane & 15);
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = co0 + wc * 32 + u * 16 + 4 * g + r;
@@ -642,7 +344,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             for (int t = 0; t < 9; ++t) d[t] = acc[t][u][r];
         }
 #undef FOSVOS_W2_ROW
-#undef FOSVOS_W2_PIECE
+#undef FOSVOS_W2_PIECES_OF_ROW
+#undef FOSVOS_W2_PIECE_ANY
 #undef FOSVOS_W2_TILE_SCALARS
 #undef FOSVOS_W2_ADVANCE
 #undef FOSVOS_W2_STAGE
@@ -735,21 +438,8 @@ int target_blocks() {  // FOSVOS_WGRAD_BLOCKS: lab switch, read once
     return v;
 }
 
-int wgrad_waves() {  // FOSVOS_WGRAD_WAVES=8: 128 co x 64 ci eight-wave workgroups where Co allows (lab switch, read once)
-    static const int v = [] {
-        const char *e = getenv("FOSVOS_WGRAD_WAVES");
-        return e && atoi(e) == 8 ? 8 : 4;
-    }();
-    return v;
-}
-
-bool wgrad_v2() {  // FOSVOS_WGRAD_V2=0: the round-2 kernel (lab switch, read at every call so that one process can A/B)
-    const char *e = getenv("FOSVOS_WGRAD_V2");
-    return !(e && atoi(e) == 0);
-}
-
 struct Plan {
-    int Cor, Cy, side, wide, tiles_x, tiles_y, n_tiles, tps, S, n_ci;
+    int Cor, Cy, side, tiles_x, tiles_y, n_tiles, tps, S, n_ci;
     size_t slab_bytes, bias_bytes;
 };
 
@@ -757,24 +447,21 @@ struct Plan {
 // time stages 1-2 get their weight gradients): 256 workgroups, one per CU, instead of the shared-chip default
 Plan make_plan(int N, int H, int W, int Ci, int Co, bool alone = false) {
     Plan p;
-    p.side = Co % 64 != 0;            // side_prep: 16 outputs in a 32-wide dy image, <1,4> workgroups
+    p.side = Co % 64 != 0;            // side_prep: 16 outputs in a 32-wide dy image, the four-wave form of the kernel
     p.Cor = p.side ? Co : roundup(Co, 64);  // slab / bias-partial rows: side_prep keeps its 16 real channels only
     p.Cy = roundup(Co, 32);
     p.tiles_x = (int)cdiv(W, 16);
     p.tiles_y = (int)cdiv(H, TH);
     p.n_tiles = p.tiles_x * p.tiles_y * N;
-    // wide (opt-in): 8-wave workgroups, 128 co x 64 ci, two waves per SIMD.  Measured: 1.55x the per-CU rate of the 4-wave
-    // form alone on the chip, but it owns its CUs (112 KB of LDS, the whole register file) and the data-gradient kernels
-    // beside it lose more than the weight-gradient stream gains: 705 vs 738 frames/s on the fine-tune step
-    p.wide = !p.side && Co % 128 == 0 && wgrad_waves() == 8;
-    const int out_blocks = p.side ? Ci / 128 : (p.Cor / (p.wide ? 128 : 64)) * (Ci / 64);
+    // workgroups per pixel split: 64 co x 64 ci each (side_prep: its 16 co x 64 ci)
+    const int out_blocks = p.side ? Ci / 64 : (p.Cor / 64) * (Ci / 64);
     int S = (int)cdiv(alone ? std::max(256, target_blocks()) : target_blocks(), out_blocks);
     if (S > p.n_tiles) S = p.n_tiles;
     if (S < 1) S = 1;
     p.tps = (int)cdiv(p.n_tiles, S);
     p.S = (int)cdiv(p.n_tiles, p.tps);
     p.slab_bytes = (size_t)p.S * 9 * p.Cor * Ci * sizeof(float);
-    p.n_ci = p.side ? Ci / 128 : Ci / 64;  // ci blocks (gridDim.y) share the bias sums of a split
+    p.n_ci = Ci / 64;  // the ci blocks of a split share out its bias sums
     p.bias_bytes = (size_t)p.S * p.n_ci * p.Cor * sizeof(float);
     return p;
 }
@@ -782,8 +469,7 @@ Plan make_plan(int N, int H, int W, int Ci, int Co, bool alone = false) {
 int check_shape(int N, int H, int W, int Ci, int Co, const char *who) {
     FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, FOSVOS_E_SHAPE, "%s: bad shape", who);
     FOSVOS_REQUIRE(Ci % BCI == 0, FOSVOS_E_SHAPE, "%s: Ci=%d must be a multiple of %d", who, Ci, BCI);
-    FOSVOS_REQUIRE(Co % 64 == 0 || (Co == 16 && Ci % 128 == 0), FOSVOS_E_SHAPE,
-                   "%s: Co=%d must be a multiple of 64, or 16 with Ci a multiple of 128", who, Co);
+    FOSVOS_REQUIRE(Co % 64 == 0 || Co == 16, FOSVOS_E_SHAPE, "%s: Co=%d must be a multiple of 64, or 16 (side_prep)", who, Co);
     FOSVOS_REQUIRE(((int64_t)N * H * W + W + 1) * std::max(Ci, roundup(Co, 32)) * 2 < 0xffffffffLL, FOSVOS_E_SHAPE,
                    "%s: a tensor of %d x %d x %d x %d bf16 exceeds the 4 GB a buffer descriptor addresses", who, N, H, W,
                    std::max(Ci, roundup(Co, 32)));
@@ -890,60 +576,34 @@ int fosvos::wgrad_impl(const uint16_t *x, const uint16_t *dy, float *dw, float *
     a.bias_part = db ? reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + p.slab_bytes) : nullptr;
     a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Cy = p.Cy; a.Cor = p.Cor;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles; a.tiles_per_split = p.tps;
-    a.S = p.S; a.n_ci = a.n_co = 0; a.xcd_order = 0;
+    a.S = p.S; a.n_ci = Ci / 64; a.n_co = p.side ? 1 : p.Cor / 64;
     {
         static const int lab = getenv("FOSVOS_WGRAD_LAB") ? atoi(getenv("FOSVOS_WGRAD_LAB")) : 0;
         a.lab = lab;
+        const char *e = getenv("FOSVOS_WGRAD_XCD");  // lab switch (read per call: one process can A/B): 0 = plain workgroup order
+        a.xcd_order = !(e && atoi(e) == 0);
     }
-#ifdef FOSVOS_WG_STAMP
-    a.stamps = g_wg_stamps;
-#endif
-    static bool once[64][4];  // per device: opt in to the dynamic LDS size
+    static bool once[64][2];  // per device: opt in to the dynamic LDS size
     const double flops = 2.0 * N * H * W * 9.0 * Ci * Co;
-    if (p.wide) {
-        using C = Cfg<4, 2>;
-        if (device >= 0 && device < 64 && !once[device][2]) {
-            FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad3x3<4, 2>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-            once[device][2] = true;
-        }
-        const dim3 grid((unsigned)p.S, (unsigned)(Ci / C::BCIW), (unsigned)(p.Cor / C::BCO));
-        FOSVOS_PROF("k_wgrad3x3<4, 2>", st, flops);
-        hipLaunchKernelGGL((k_wgrad3x3<4, 2>), grid, dim3(C::NT), C::LDS_BYTES, st, a);
-    } else if (!p.side && wgrad_v2()) {
-        if (device >= 0 && device < 64 && !once[device][3]) {
-            FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(v2::k_wgrad3x3_v2),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, v2::LDS_BYTES));
-            once[device][3] = true;
-        }
-        a.S = p.S; a.n_ci = Ci / 64; a.n_co = p.Cor / 64;
-        {
-            const char *e = getenv("FOSVOS_WGRAD_XCD");  // lab switch: 0 = plain (split fastest) workgroup order
-            a.xcd_order = !(e && atoi(e) == 0);
-        }
-        const dim3 grid((unsigned)(p.S * a.n_ci * a.n_co));
-        FOSVOS_PROF("k_wgrad3x3_v2", st, flops);
-        hipLaunchKernelGGL(v2::k_wgrad3x3_v2, grid, dim3(v2::NT), v2::LDS_BYTES, st, a);
-    } else if (!p.side) {
-        using C = Cfg<2, 2>;
-        if (device >= 0 && device < 64 && !once[device][0]) {
-            FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad3x3<2, 2>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-            once[device][0] = true;
-        }
-        const dim3 grid((unsigned)p.S, (unsigned)(Ci / C::BCIW), (unsigned)(p.Cor / C::BCO));
-        FOSVOS_PROF("k_wgrad3x3<2, 2>", st, flops);
-        hipLaunchKernelGGL((k_wgrad3x3<2, 2>), grid, dim3(256), C::LDS_BYTES, st, a);
-    } else {
-        using C = Cfg<1, 4>;
+    const dim3 grid((unsigned)(p.S * a.n_ci * a.n_co));
+    if (p.side) {
+        using C2 = v2::Cfg2<true>;
         if (device >= 0 && device < 64 && !once[device][1]) {
-            FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad3x3<1, 4>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+            FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(v2::k_wgrad3x3_v2<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, C2::LDS_BYTES));
             once[device][1] = true;
         }
-        const dim3 grid((unsigned)p.S, (unsigned)(Ci / C::BCIW), 1);
-        FOSVOS_PROF("k_wgrad3x3<1, 4>", st, flops);
-        hipLaunchKernelGGL((k_wgrad3x3<1, 4>), grid, dim3(256), C::LDS_BYTES, st, a);
+        FOSVOS_PROF("k_wgrad3x3_v2<true>", st, flops);
+        hipLaunchKernelGGL(v2::k_wgrad3x3_v2<true>, grid, dim3(C2::NT), C2::LDS_BYTES, st, a);
+    } else {
+        using C2 = v2::Cfg2<false>;
+        if (device >= 0 && device < 64 && !once[device][0]) {
+            FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(v2::k_wgrad3x3_v2<false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, C2::LDS_BYTES));
+            once[device][0] = true;
+        }
+        FOSVOS_PROF("k_wgrad3x3_v2<false>", st, flops);
+        hipLaunchKernelGGL(v2::k_wgrad3x3_v2<false>, grid, dim3(C2::NT), C2::LDS_BYTES, st, a);
     }
     FOSVOS_LAUNCH_CHECK();
     return finish_or_queue(p, a.slabs, a.bias_part, dw, db, Ci, Co, accumulate, reduce, device, st);
