@@ -1,6 +1,6 @@
 // Diagnostic build of the implicit-GEMM conv kernel with in-kernel clock stamps (never shipped):
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DFOSVOS_STAMP tools/igemm_lab.hip -o build/igemm_lab
-//   build/igemm_lab H W Ci Co [reps]
+//   build/igemm_lab H W Ci Co [reps] [frames per launch]
 // Times fosvos_conv3x3_fwd on random data with HIP events, then prints per-phase medians (shader
 // clocks, wave 0 of each workgroup) and the distribution of workgroup start/end times.
 #include "../fosvos_amd/csrc/conv_igemm.hip"
@@ -37,12 +37,13 @@ static uint16_t rnd_bf16(uint32_t &s, float scale) {
 
 int main(int argc, char **argv) {
     if (argc < 5) {
-        fprintf(stderr, "usage: igemm_lab H W Ci Co [reps]\n");
+        fprintf(stderr, "usage: igemm_lab H W Ci Co [reps] [frames]\n");
         return 2;
     }
     const int H = atoi(argv[1]), W = atoi(argv[2]), Ci = atoi(argv[3]), Co = atoi(argv[4]);
     const int reps = argc > 5 ? atoi(argv[5]) : 20;
-    const size_t nx = (size_t)H * W * Ci, ny = (size_t)H * W * Co;
+    const int N = argc > 6 ? atoi(argv[6]) : 1;  // frames per launch
+    const size_t nx = (size_t)N * H * W * Ci, ny = (size_t)N * H * W * Co;
     const size_t nw = (size_t)(Ci / 32) * 36 * Co * 8;
     std::vector<uint16_t> hx(nx), hw(nw);
     uint32_t seed = 12345;
@@ -58,12 +59,12 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dw, hw.data(), nw * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, hb.data(), Co * 4, hipMemcpyHostToDevice));
-    const size_t wsb = fosvos_conv3x3_workspace_bytes(1, H, W, Ci, Co);
+    const size_t wsb = fosvos_conv3x3_workspace_bytes(N, H, W, Ci, Co);
     void *ws = nullptr;
     if (wsb) CK(hipMalloc(&ws, wsb));
-    const ConvPlan plan = make_plan(1, H, W, Ci, Co);
+    const ConvPlan plan = make_plan(N, H, W, Ci, Co);
     const int th = plan.tile == kSmall ? 4 : plan.tile == kSquare ? 16 : 8, tw = plan.tile == kBig ? 32 : 16;
-    const int64_t nwg = cdiv(W, tw) * cdiv(H, th) * (Co / 64) * plan.k_splits;
+    const int64_t nwg = (int64_t)N * cdiv(W, tw) * cdiv(H, th) * (Co / 64) * plan.k_splits;
     printf("conv %dx%d Ci=%d Co=%d  tile=%d k_splits=%d  workgroups=%lld\n", H, W, Ci, Co, (int)plan.tile,
            plan.k_splits, (long long)nwg);
     unsigned long long *dst;
@@ -75,18 +76,18 @@ int main(int argc, char **argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     for (int i = 0; i < 5; ++i)
-        if (fosvos_conv3x3_fwd(dx, dw, db, dy, 1, H, W, Ci, Co, FOSVOS_CONV_RELU, ws, wsb, 0, st)) return 1;
+        if (fosvos_conv3x3_fwd(dx, dw, db, dy, N, H, W, Ci, Co, FOSVOS_CONV_RELU, ws, wsb, 0, st)) return 1;
     CK(hipEventRecord(e0, st));
     for (int i = 0; i < reps; ++i)
-        if (fosvos_conv3x3_fwd(dx, dw, db, dy, 1, H, W, Ci, Co, FOSVOS_CONV_RELU, ws, wsb, 0, st)) return 1;
+        if (fosvos_conv3x3_fwd(dx, dw, db, dy, N, H, W, Ci, Co, FOSVOS_CONV_RELU, ws, wsb, 0, st)) return 1;
     CK(hipEventRecord(e1, st));
     CK(hipStreamSynchronize(st));
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    const double us = ms * 1e3 / reps, tf = 2.0 * H * W * 9.0 * Ci * Co / us * 1e-6;
+    const double us = ms * 1e3 / reps, tf = 2.0 * N * H * W * 9.0 * Ci * Co / us * 1e-6;
     printf("no stamps: %.1f us/launch  %.1f TFLOP/s\n", us, tf);
     g_stamps = dst;
-    if (fosvos_conv3x3_fwd(dx, dw, db, dy, 1, H, W, Ci, Co, FOSVOS_CONV_RELU, ws, wsb, 0, st)) return 1;
+    if (fosvos_conv3x3_fwd(dx, dw, db, dy, N, H, W, Ci, Co, FOSVOS_CONV_RELU, ws, wsb, 0, st)) return 1;
     CK(hipStreamSynchronize(st));
     std::vector<unsigned long long> hs(nwg * 16);
     CK(hipMemcpy(hs.data(), dst, nwg * 16 * 8, hipMemcpyDeviceToHost));

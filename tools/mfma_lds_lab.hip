@@ -1,0 +1,136 @@
+// Lab tool (never shipped): the ceiling of an LDS-fed MFMA loop on gfx950, without any global traffic.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/mfma_lds_lab.hip -o build/mfma_lds_lab && build/mfma_lds_lab
+// A workgroup of 4 waves keeps a pixel image (4 k-groups x NPIX x 16 B) and a weight image (9 taps x 4 k-groups x BN x 16 B) in
+// LDS, as the implicit-GEMM conv does, and each wave multiplies its MF x NF fragments (16x16x32 bf16) for CHUNKS x 9 taps:
+// MF + NF ds_read_b128 per MF * NF MFMAs.  Variants: wave tile, workgroups per CU (forced by the LDS request), fragment
+// reads skipped (MFMA-only), MFMAs skipped (LDS-only).  Prints achieved TFLOP/s and the share of the 2.5 PFLOP/s peak.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define CK(x)                                                                            \
+    do {                                                                                 \
+        hipError_t e = (x);                                                              \
+        if (e != hipSuccess) {                                                           \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));                       \
+            exit(1);                                                                     \
+        }                                                                                \
+    } while (0)
+
+// MODE 0: reads + MFMAs, 1: MFMAs only (fragments read once), 2: reads only
+template <int MF, int NF, int MODE, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_loop(float *out, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    constexpr int TW = 32, HALO_W = TW + 2, NPIX_PAD = ((4 * MF * 16 / TW + 2) * HALO_W + 3 + 15) / 16 * 16;
+    constexpr int BN = 16 * NF;
+    uint4 *sA = smem, *sB = smem + 4 * NPIX_PAD;  // the weight image holds three taps (the lab measures the loop, not the footprint)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4 * NPIX_PAD + 12 * BN; i += 256) {  // random mantissas and signs, |v| in [1, 2): realistic toggling for DVFS
+        unsigned h = (i + 1) * 2654435761u;
+        uint4 v;
+        h ^= h >> 15; h *= 2246822519u; v.x = (h & 0x807f807fu) | 0x3f803f80u;
+        h ^= h >> 13; h *= 3266489917u; v.y = (h & 0x807f807fu) | 0x3f803f80u;
+        h ^= h >> 16; h *= 668265263u; v.z = (h & 0x807f807fu) | 0x3f803f80u;
+        h ^= h >> 15; h *= 374761393u; v.w = (h & 0x807f807fu) | 0x3f803f80u;
+        smem[i] = v;
+    }
+    __syncthreads();
+    int a_base[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int pb = (wave * MF + i) * 16;
+        a_base[i] = (lane >> 4) * NPIX_PAD + (pb / TW) * HALO_W + pb % TW + (lane & 15);
+    }
+    const int b_base = (lane >> 4) * BN + (lane & 15);
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[MF], bfr[2][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) af[i] = __builtin_bit_cast(bf16x8, sA[a_base[i]]);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) bfr[0][j] = bfr[1][j] = __builtin_bit_cast(bf16x8, sB[b_base + j * 16]);
+    for (int cc = 0; cc < chunks; ++cc) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int nt = (tap + 1) % 9;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                if constexpr (MODE != 2) {
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tap & 1][j], af[i], acc[i][j], 0, 0, 0);
+                }
+                if constexpr (MODE != 1) {
+                    af[i] = __builtin_bit_cast(bf16x8, sA[a_base[i] + (nt / 3) * HALO_W + nt % 3]);
+                    constexpr int per_row = (NF + MF - 1) / MF;
+#pragma unroll
+                    for (int j = i * per_row; j < (i + 1) * per_row && j < NF; ++j)
+                        bfr[(tap + 1) & 1][j] = __builtin_bit_cast(bf16x8, sB[b_base + (nt % 3) * 4 * BN + j * 16]);
+                    if constexpr (MODE == 2) {
+#pragma unroll
+                        for (int j = 0; j < NF; ++j) acc[i][j][0] += (float)af[i][0] + (float)bfr[(tap + 1) & 1][j][0];
+                    }
+                }
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 12345.678f) out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int MF, int NF, int MODE, int WPE>
+void run(const char *name, int wg_per_cu, float *out) {
+    const int chunks = 64, grid = 256 * wg_per_cu * 4;
+    const int lds = 160 * 1024 / wg_per_cu - 1024;  // forces wg_per_cu workgroups per CU
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_loop<MF, NF, MODE, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_loop<MF, NF, MODE, WPE>), dim3(grid), dim3(256), lds, 0, out, chunks);
+    CK(hipDeviceSynchronize());
+    const int reps = 5;
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_loop<MF, NF, MODE, WPE>), dim3(grid), dim3(256), lds, 0, out, chunks);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)reps * grid * 4 * chunks * 9 * MF * NF * (16.0 * 16 * 32 * 2);
+    const double lds_bytes = (double)reps * grid * 4 * chunks * 9 * (MF + NF) * 1024.0;
+    const double tf = flops / (ms * 1e-3) / 1e12;
+    printf("%-34s MF=%d NF=%d wg/cu=%d  %8.3f ms  %7.1f TFLOP/s (%.3f of 2500)  LDS reads %6.1f TB/s\n", name, MF, NF, wg_per_cu, ms / reps,
+           MODE == 2 ? 0.0 : tf, MODE == 2 ? 0.0 : tf / 2500.0, MODE == 1 ? 0.0 : lds_bytes / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+    float *out;
+    CK(hipMalloc(&out, 64 << 20));
+    run<4, 4, 1, 2>("mfma only 64x64", 2, out);
+    run<4, 4, 1, 1>("mfma only 64x64", 1, out);
+    run<4, 4, 2, 2>("lds only 64x64", 2, out);
+    run<4, 4, 2, 1>("lds only 64x64", 1, out);
+    run<4, 4, 0, 2>("igemm-like 64x64", 2, out);
+    run<4, 4, 0, 1>("igemm-like 64x64", 1, out);
+    run<4, 4, 0, 3>("igemm-like 64x64", 3, out);
+    run<8, 4, 0, 2>("128x64 per wave", 2, out);
+    run<8, 4, 0, 1>("128x64 per wave", 1, out);
+    run<4, 8, 0, 2>("64x128 per wave", 2, out);
+    run<4, 8, 0, 1>("64x128 per wave", 1, out);
+    run<8, 8, 0, 1>("128x128 per wave", 1, out);
+    run<2, 4, 0, 2>("32x64 per wave", 2, out);
+    run<2, 4, 0, 4>("32x64 per wave", 4, out);
+    return 0;
+}
