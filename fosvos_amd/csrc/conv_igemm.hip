@@ -624,7 +624,11 @@ ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
         // 256-pixel tiles as soon as there is one per CU (measured: 420 workgroups of 8x32 beat 840 of 8x16 by 8 % at
         // 120x214x256 alone; at 60x107x512, 256 of them beat 448 of 8x16 by 1 % of the whole step beside the wgrad
         // stream, which fills the second slot of each CU); below that the 128-pixel tile, 3 per CU
-        if (blocks(8, 32, 64) >= kMinBlocks / 2) {
+        // ... unless the 128-pixel tiles still fit in ONE round (3 per CU = 768): five frames of the 30x54x512 layers are 320
+        // big workgroups (62 % of the 512 slots, 16 chunks each) or 640 small ones: 53 against 60 us per launch alone
+        static const bool one_round = !(getenv("FOSVOS_MID_ONE_ROUND") && atoi(getenv("FOSVOS_MID_ONE_ROUND")) == 0);
+        const bool mid_fits_a_round = one_round && blocks(8, 16, 64) <= 768 && blocks(8, 32, 64) < kMinBlocks * 3 / 4;
+        if (blocks(8, 32, 64) >= kMinBlocks / 2 && !mid_fits_a_round) {
             // ... as 8 x 32 or as 16 x 16 pixels, whichever overhangs the map less (a tile computes all of its 256 pixels:
             // 60 x 107 is 64 x 128 = 8192 pixels of work in 8 x 32 tiles, 64 x 112 = 7168 in 16 x 16 ones)
             const int64_t area_wide = cdiv(H, 8) * 8 * cdiv(W, 32) * 32, area_sq = cdiv(H, 16) * 16 * cdiv(W, 16) * 16;
