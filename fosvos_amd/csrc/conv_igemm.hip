@@ -50,6 +50,10 @@ struct ConvArgs {
     int k_splits;      // > 1: blockIdx.z owns a range of K chunks and writes raw fp32 partials
     int chunks_per_split;
     float *partial;    // [k_splits][N*H*W][Cout] fp32 when k_splits > 1
+    // Reciprocal multipliers for the workgroup -> (tile, channel block) arithmetic (see fast_div): four runtime divisions cost
+    // the prologue of every workgroup a reciprocal on the vector ALU and a round trip to the scalar unit each.  0 = divide.
+    unsigned m_ncb, m_nt, m_tx, m_ty;
+    int n_t;           // pixel tiles of the launch (swizzled grids)
 #ifdef FOSVOS_STAMP
     unsigned long long *stamps;  // diagnostic build only (tools/igemm_lab.hip): 16 slots per workgroup
 #endif
@@ -69,6 +73,13 @@ unsigned long long *g_stamps = nullptr;
 #define FOSVOS_STAMP_AT(i)
 #define FOSVOS_STAMP_RT(i)
 #endif
+
+// n / d for n * d < 2^32 with m = floor(2^32 / d) + 1 (host side: recip_mul; exact: the error n (m d - 2^32) / (d 2^32) stays
+// below 1 / d); m == 0 means "no multiplier" (d == 1, or a launch too large for the bound): plain division.
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned m) { return m ? __umulhi(n, m) : n / d; }
+unsigned recip_mul(int64_t n_max, int64_t d) {
+    return (d >= 2 && n_max * d < (int64_t(1) << 32)) ? (unsigned)((int64_t(1) << 32) / d + 1) : 0u;
+}
 
 template <int TH_, int TW_, int BN_, int WM_, int WN_>
 struct Tile {
@@ -153,16 +164,16 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
     int t = blockIdx.x;
     int cb = blockIdx.y;
     if (a.swizzle) {
-        const int n_wg = gridDim.x, n_cb = a.Cout / T::BN, n_t = n_wg / n_cb;
+        const int n_wg = gridDim.x, n_cb = a.Cout / T::BN, n_t = a.n_t;
         const int q8 = n_wg >> 3, r8 = n_wg & 7, xcd = t & 7;
         const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (t >> 3);  // bijective for any n_wg
-        if (a.swizzle == 1) { cb = swz % n_cb; t = swz / n_cb; }
-        else { cb = swz / n_t; t = swz - cb * n_t; }
+        if (a.swizzle == 1) { t = fast_div(swz, n_cb, a.m_ncb); cb = swz - t * n_cb; }
+        else { cb = fast_div(swz, n_t, a.m_nt); t = swz - cb * n_t; }
     }
-    const int tx_i = t % a.tiles_x;
-    t /= a.tiles_x;
-    const int ty_i = t % a.tiles_y;
-    const int n = t / a.tiles_y;
+    const int t_row = fast_div(t, a.tiles_x, a.m_tx);   // (frame, tile row)
+    const int tx_i = t - t_row * a.tiles_x;
+    const int n = fast_div(t_row, a.tiles_y, a.m_ty);
+    const int ty_i = t_row - n * a.tiles_y;
     const int y0 = ty_i * T::TH, x0 = tx_i * T::TW;
     const int n0 = cb * T::BN;
     const int H = a.H, W = a.W, Cin = a.Cin;
@@ -704,6 +715,14 @@ int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st, int in_ch) 
         // not fit an L2 beside the input tiles; mode 2 -1 %.  On the step +0.6 %.
         a.swizzle = swz_env >= 0 ? swz_env : (tiles * n_cb >= 64 ? 1 : 0);
         if (tiles * n_cb > 0x7fffffff) a.swizzle = 0;
+    }
+    {
+        const int64_t n_cb = a.Cout / T::BN, n_wg = tiles * n_cb;
+        a.n_t = (int)tiles;
+        a.m_ncb = recip_mul(n_wg, n_cb);
+        a.m_nt = recip_mul(n_wg, tiles);
+        a.m_tx = recip_mul(tiles, a.tiles_x);
+        a.m_ty = recip_mul(tiles, a.tiles_y);
     }
     const dim3 grid = a.swizzle ? dim3((unsigned)(tiles * (a.Cout / T::BN)), 1u, (unsigned)plan.k_splits)
                                 : dim3((unsigned)tiles, (unsigned)(a.Cout / T::BN), (unsigned)plan.k_splits);

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     constexpr int BN = 16 * NF;
     uint4 *sA = smem, *sB = smem + 4 * NPIX_PAD;  // the weight image holds three taps (the lab measures the loop, not the footprint)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = tid; i < 4 * NPIX_PAD + 12 * BN; i += 256) {  // random mantissas and signs, |v| in [1, 2): realistic toggling for DVFS
         unsigned h = (i + 1) * 2654435761u;
         uint4 v;
@@ -89,11 +90,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
         for (int j = 0; j < NF; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     if (s == 12345.678f) out[blockIdx.x * 256 + tid] = s;
+    if (blockIdx.x == 0 && tid == 0) {  // shader clocks per 100-MHz tick over this workgroup's life
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(out + (60 << 20) / 4);
+        st[0] = __builtin_amdgcn_s_memtime() - c0;
+        st[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
 template <int MF, int NF, int MODE, int WPE>
-void run(const char *name, int wg_per_cu, float *out) {
-    const int chunks = 64, grid = 256 * wg_per_cu * 4;
+void run(const char *name, int wg_per_cu, float *out, int chunks = 64) {
+    const int grid = 256 * wg_per_cu * 4;
     const int lds = 160 * 1024 / wg_per_cu - 1024;  // forces wg_per_cu workgroups per CU
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_loop<MF, NF, MODE, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1;
@@ -111,8 +117,113 @@ void run(const char *name, int wg_per_cu, float *out) {
     const double flops = (double)reps * grid * 4 * chunks * 9 * MF * NF * (16.0 * 16 * 32 * 2);
     const double lds_bytes = (double)reps * grid * 4 * chunks * 9 * (MF + NF) * 1024.0;
     const double tf = flops / (ms * 1e-3) / 1e12;
-    printf("%-34s MF=%d NF=%d wg/cu=%d  %8.3f ms  %7.1f TFLOP/s (%.3f of 2500)  LDS reads %6.1f TB/s\n", name, MF, NF, wg_per_cu, ms / reps,
-           MODE == 2 ? 0.0 : tf, MODE == 2 ? 0.0 : tf / 2500.0, MODE == 1 ? 0.0 : lds_bytes / (ms * 1e-3) / 1e12);
+    unsigned long long st[2];
+    CK(hipMemcpy(st, reinterpret_cast<char *>(out) + (60 << 20), 16, hipMemcpyDeviceToHost));
+    printf("%-34s MF=%d NF=%d wg/cu=%d  %8.3f ms  %7.1f TFLOP/s (%.3f of 2500)  LDS reads %6.1f TB/s  clock %.0f MHz\n", name, MF, NF, wg_per_cu, ms / reps,
+           MODE == 2 ? 0.0 : tf, MODE == 2 ? 0.0 : tf / 2500.0, MODE == 1 ? 0.0 : lds_bytes / (ms * 1e-3) / 1e12, 100.0 * st[0] / st[1]);
+}
+
+// The same 64 x 64 wave tile on 32x32x16 MFMAs (2 x 2 per k-half, 16 accumulator registers each): the operand bytes per
+// flop read from the register file halve.  MODE as above.
+template <int MODE, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_loop32(float *out, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    constexpr int TW = 32, HALO_W = TW + 2, NPIX_PAD = ((4 * 4 * 16 / TW + 2) * HALO_W + 3 + 15) / 16 * 16, BN = 64;
+    uint4 *sA = smem, *sB = smem + 4 * NPIX_PAD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = tid; i < 4 * NPIX_PAD + 12 * BN; i += 256) {
+        unsigned h = (i + 1) * 2654435761u;
+        uint4 v;
+        h ^= h >> 15; h *= 2246822519u; v.x = (h & 0x807f807fu) | 0x3f803f80u;
+        h ^= h >> 13; h *= 3266489917u; v.y = (h & 0x807f807fu) | 0x3f803f80u;
+        h ^= h >> 16; h *= 668265263u; v.z = (h & 0x807f807fu) | 0x3f803f80u;
+        h ^= h >> 15; h *= 374761393u; v.w = (h & 0x807f807fu) | 0x3f803f80u;
+        smem[i] = v;
+    }
+    __syncthreads();
+    // fragment (rb, h): 32 pixels (row block rb of the wave's 2 tile rows) x k-half h; lane -> pixel lane % 32, k-group 2 h + lane / 32
+    int a_base[2], b_base[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) a_base[rb] = (lane >> 5) * NPIX_PAD + (wave * 2 + rb) * HALO_W + (lane & 31);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) b_base[cb] = (lane >> 5) * BN + cb * 32 + (lane & 31);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bf16x8 af[2][2][2], bfr[2][2][2];  // [buffer][k-half][block]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            af[0][h][b] = af[1][h][b] = __builtin_bit_cast(bf16x8, sA[a_base[b] + 2 * h * NPIX_PAD]);
+            bfr[0][h][b] = bfr[1][h][b] = __builtin_bit_cast(bf16x8, sB[b_base[b] + 2 * h * BN]);
+        }
+    for (int cc = 0; cc < chunks; ++cc) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int nt = (tap + 1) % 9, cur = tap & 1, nxt = cur ^ 1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if constexpr (MODE != 2) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][h][j], af[cur][h][i], acc[i][j], 0, 0, 0);
+                }
+                if constexpr (MODE != 1) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        af[nxt][h][b] = __builtin_bit_cast(bf16x8, sA[a_base[b] + 2 * h * NPIX_PAD + (nt / 3) * HALO_W + nt % 3]);
+                        bfr[nxt][h][b] = __builtin_bit_cast(bf16x8, sB[b_base[b] + (nt % 3) * 4 * BN + 2 * h * BN]);
+                    }
+                }
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+    if (s == 12345.678f) out[blockIdx.x * 256 + tid] = s;
+    if (blockIdx.x == 0 && tid == 0) {  // shader clocks per 100-MHz tick over this workgroup's life
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(out + (60 << 20) / 4);
+        st[0] = __builtin_amdgcn_s_memtime() - c0;
+        st[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+
+template <int MODE, int WPE>
+void run32(const char *name, int wg_per_cu, float *out, int chunks = 64) {
+    const int grid = 256 * wg_per_cu * 4;
+    const int lds = 160 * 1024 / wg_per_cu - 1024;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_loop32<MODE, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_loop32<MODE, WPE>), dim3(grid), dim3(256), lds, 0, out, chunks);
+    CK(hipDeviceSynchronize());
+    const int reps = 5;
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_loop32<MODE, WPE>), dim3(grid), dim3(256), lds, 0, out, chunks);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)reps * grid * 4 * chunks * 9 * 8 * (32.0 * 32 * 16 * 2);
+    const double tf = flops / (ms * 1e-3) / 1e12;
+    unsigned long long st[2];
+    CK(hipMemcpy(st, reinterpret_cast<char *>(out) + (60 << 20), 16, hipMemcpyDeviceToHost));
+    printf("%-34s 32x32x16 wg/cu=%d  %8.3f ms  %7.1f TFLOP/s (%.3f of 2500)  clock %.0f MHz\n", name, wg_per_cu, ms / reps, MODE == 2 ? 0.0 : tf,
+           MODE == 2 ? 0.0 : tf / 2500.0, 100.0 * st[0] / st[1]);
 }
 
 int main() {
@@ -132,5 +243,14 @@ int main() {
     run<8, 8, 0, 1>("128x128 per wave", 1, out);
     run<2, 4, 0, 2>("32x64 per wave", 2, out);
     run<2, 4, 0, 4>("32x64 per wave", 4, out);
+    // steady-state clocks: ~50 ms per measurement
+    printf("-- long runs (1024 chunks per workgroup)\n");
+    run<4, 4, 1, 2>("mfma only 64x64", 2, out, 1024);
+    run32<1, 2>("mfma only 64x64", 2, out, 1024);
+    run<4, 4, 0, 2>("igemm-like 64x64", 2, out, 1024);
+    run32<0, 2>("igemm-like 64x64", 2, out, 1024);
+    run<2, 4, 0, 2>("32x64 per wave", 2, out, 1024);
+    run<4, 4, 0, 1>("igemm-like 64x64", 1, out, 1024);
+    run32<0, 1>("igemm-like 64x64", 1, out, 1024);
     return 0;
 }
