@@ -10,11 +10,12 @@ using namespace fosvos;
 
 namespace {
 __global__ __launch_bounds__(256) void k_sgd(const fosvos_sgd_entry *__restrict__ table, float momentum,
-                                              int first_step) {
+                                              int flags) {
+    const bool first_step = flags & FOSVOS_SGD_FIRST_STEP, zero = flags & FOSVOS_SGD_ZERO_GRAD;
     const fosvos_sgd_entry e = table[blockIdx.y];
     if (e.grad == nullptr || e.numel <= 0) return;
     float *__restrict__ p = e.param;
-    const float *__restrict__ g = e.grad;
+    float *__restrict__ g = const_cast<float *>(e.grad);
     float *__restrict__ m = e.momentum_buf;
     const float lr = e.lr, wd = e.weight_decay;
     const int64_t n = e.numel;
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(256) void k_sgd(const fosvos_sgd_entry *__restrict_
         }
         reinterpret_cast<float4 *>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
         reinterpret_cast<float4 *>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        if (zero) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int64_t i = n4 * 4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -40,6 +42,7 @@ __global__ __launch_bounds__(256) void k_sgd(const fosvos_sgd_entry *__restrict_
         const float mm = first_step ? d : momentum * m[i] + d;
         m[i] = mm;
         p[i] = p[i] - lr * mm;
+        if (zero) g[i] = 0.f;
     }
 }
 }  // namespace

@@ -496,7 +496,8 @@ def cbce_loss(logits: torch.Tensor, label: torch.Tensor, size_average: bool = Tr
     return loss, grad
 
 
-def cbce_loss_frames(logits: torch.Tensor, label: torch.Tensor, size_average: bool = True, want_grad: bool = True):
+def cbce_loss_frames(logits: torch.Tensor, label: torch.Tensor, size_average: bool = True, want_grad: bool = True,
+                     grad_scale: float = 1.0):
     """The loss of every frame of [N,1,H,W] logits on its own: ([N] losses, grad like logits or None), one set of launches.
     Frames whose element count is not a multiple of 4 go through one call per frame (16-byte alignment of the kernels)."""
     _need(logits, _F32, "cbce_loss_frames logits"); _need(label, _F32, "cbce_loss_frames label")
@@ -505,7 +506,8 @@ def cbce_loss_frames(logits: torch.Tensor, label: torch.Tensor, size_average: bo
     n = logits.shape[0]
     per = logits.numel() // n
     if per % 4 or logits.data_ptr() % 16 or label.data_ptr() % 16:
-        parts = [cbce_loss(logits[i:i + 1], label[i:i + 1], size_average=size_average, want_grad=want_grad) for i in range(n)]
+        parts = [cbce_loss(logits[i:i + 1], label[i:i + 1], size_average=size_average, grad_scale=grad_scale,
+                           want_grad=want_grad) for i in range(n)]
         return torch.stack([p[0] for p in parts]), (torch.cat([p[1] for p in parts]) if want_grad else None)
     L = lib()
     losses = torch.empty((n,), dtype=_F32, device=logits.device)
@@ -513,7 +515,7 @@ def cbce_loss_frames(logits: torch.Tensor, label: torch.Tensor, size_average: bo
     ws, wsn = _WS.get(n * L.fosvos_cbce_workspace_bytes(per), logits.device)
     dev, st = _ctx(logits)
     t0 = _pb()
-    check(L.fosvos_cbce_loss_frames(logits.data_ptr(), label.data_ptr(), per, n, 1 if size_average else 0, 1.0,
+    check(L.fosvos_cbce_loss_frames(logits.data_ptr(), label.data_ptr(), per, n, 1 if size_average else 0, float(grad_scale),
                                     losses.data_ptr(), _p(grad), ws, wsn, dev, st), "cbce_loss_frames")
     _pe(t0, "cbce_loss", 0.0, logits.numel() * (16 if want_grad else 12))
     return losses, grad

@@ -26,10 +26,12 @@ class FusedSGD(optim.SGD):
         self._tables = {}  # tag -> the parameter table of that subset: entries, pinned staging copy, device copy, upload event
 
     @torch.no_grad()
-    def step(self, closure=None, only=None, tag="all"):
+    def step(self, closure=None, only=None, tag="all", zero_grad=False):
         """``only``: restrict this call to these parameters (an extension for loops that step parts of the model as soon as
         their gradients are final; every parameter must still be stepped exactly once per optimizer step by the caller).
-        ``tag`` names the subset: the device-side table of a subset is kept under its tag and re-sent only when it changes."""
+        ``tag`` names the subset: the device-side table of a subset is kept under its tag and re-sent only when it changes.
+        ``zero_grad``: the gradients of the stepped parameters are zeroed by the same kernel (``step(); zero_grad()`` of the
+        reference's loops as one pass over the gradients; their ``.grad`` tensors stay allocated and hold zeros)."""
         only_ids = None if only is None else {id(p) for p in only}
         loss = None
         if closure is not None:
@@ -40,6 +42,7 @@ class FusedSGD(optim.SGD):
         device = None
         max_numel = 0
         keep_alive = []
+        zero_after = []
         updated = []
         for group in self.param_groups:
             if group.get("dampening", 0) != 0 or group.get("nesterov", False):
@@ -60,6 +63,8 @@ class FusedSGD(optim.SGD):
                 if g.dtype != torch.float32 or not g.is_contiguous():
                     g = g.contiguous().float()
                     keep_alive.append(g)
+                    if zero_grad:  # the kernel would zero the copy
+                        zero_after.append(p.grad)
                 st = self.state[p]
                 buf = st.get("momentum_buffer")
                 if buf is None:
@@ -94,11 +99,13 @@ class FusedSGD(optim.SGD):
             tab["event"].record()
             tab["entries"] = entries
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        check(lib().fosvos_sgd_momentum_step(tab["dev"].data_ptr(), n, max_numel, momentum, 0, idx,
+        check(lib().fosvos_sgd_momentum_step(tab["dev"].data_ptr(), n, max_numel, momentum, 2 if zero_grad else 0, idx,
                                              torch.cuda.current_stream(idx).cuda_stream), "sgd_momentum_step")
         # the kernel wrote through raw pointers: tell torch the tensors changed, so that version-keyed caches
         # (the packed bf16 weight images) and autograd's saved-tensor checks see the update
         for p in updated:
             torch.autograd.graph.increment_version(p)
+        for g in zero_after:
+            g.zero_()
         del keep_alive
         return loss

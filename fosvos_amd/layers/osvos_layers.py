@@ -26,14 +26,39 @@ def sigmoid_np(x):
     return 1 / (1 + np.exp(-x))
 
 
+def _seed_of(backward_seed):
+    """(data_ptr, value) of an announced backward seed, (None, 1.0) without one."""
+    if backward_seed is None:
+        return None, 1.0
+    tensor, value = backward_seed
+    return tensor.data_ptr(), float(value)
+
+
+def _scaled(ctx, g):
+    """d(loss)/d(logits) times the incoming gradient.  With an announced seed the kernel already wrote the gradient times
+    that value: the very tensor that was announced needs no multiplication, anything else is divided by the value first."""
+    global seed_hits
+    if ctx.seed_ptr is None:
+        return ctx.grad * g.reshape(-1, *([1] * (ctx.grad.dim() - 1))) if g.dim() else ctx.grad * g
+    if g.data_ptr() == ctx.seed_ptr:
+        seed_hits += 1
+        return ctx.grad
+    g = g / ctx.seed_value
+    return ctx.grad * g.reshape(-1, *([1] * (ctx.grad.dim() - 1))) if g.dim() else ctx.grad * g
+
+
+seed_hits = 0  # backward passes that found their gradient already scaled (tests read it)
+
+
 class _CBCELoss(torch.autograd.Function):
     """Loss value and d(loss)/d(logits) come out of the same kernel pass; backward only scales."""
 
     @staticmethod
-    def forward(ctx, output, label, size_average, batch_counts=None):
+    def forward(ctx, output, label, size_average, batch_counts=None, backward_seed=None):
+        ctx.seed_ptr, ctx.seed_value = _seed_of(backward_seed)
         loss, grad = ops.cbce_loss(output.contiguous().float(), label.contiguous().float(),
-                                   size_average=bool(size_average), want_grad=output.requires_grad,
-                                   batch_counts=batch_counts)
+                                   size_average=bool(size_average), grad_scale=ctx.seed_value,
+                                   want_grad=output.requires_grad, batch_counts=batch_counts)
         ctx.grad = grad
         ctx.shape = output.shape
         return loss
@@ -41,11 +66,11 @@ class _CBCELoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if ctx.grad is None:
-            return None, None, None, None
-        return (ctx.grad * g).reshape(ctx.shape), None, None, None
+            return None, None, None, None, None
+        return _scaled(ctx, g).reshape(ctx.shape), None, None, None, None
 
 
-def class_balanced_cross_entropy_loss(output, label, size_average=True, batch_counts=None):
+def class_balanced_cross_entropy_loss(output, label, size_average=True, batch_counts=None, backward_seed=None):
     """Class-balanced cross entropy loss (same contract as the reference).
 
     Args:
@@ -55,6 +80,10 @@ def class_balanced_cross_entropy_loss(output, label, size_average=True, batch_co
         batch when ``output`` is one rank's shard of it (``parallel.batch_label_counts``): the reference balances the
         classes over the batch tensor (src/layers/osvos_layers.py:28-39), so a shard needs the batch's counts for the
         ranks' losses to add up to the single-process value.  None: count ``label`` itself (the reference's behaviour).
+    backward_seed: (extension) ``(tensor, value)`` - the caller announces that it will call ``loss.backward(tensor)`` and
+        that every element of ``tensor`` equals ``value`` (the online loop's 1 / nAveGrad): the loss kernel then writes the
+        gradient already multiplied, and the backward pass of that very tensor launches nothing.  Any other incoming
+        gradient is still handled correctly (divided by ``value`` first).
     Returns:
     0-dim tensor with the loss; reductions run over the whole batch tensor."""
     if not output.is_cuda:
@@ -65,7 +94,7 @@ def class_balanced_cross_entropy_loss(output, label, size_average=True, batch_co
     if tuple(label.shape) != tuple(output.shape):
         raise ValueError("class_balanced_cross_entropy_loss: output {} vs label {}".format(
             tuple(output.shape), tuple(label.shape)))
-    return _CBCELoss.apply(output, label, size_average, batch_counts)
+    return _CBCELoss.apply(output, label, size_average, batch_counts, backward_seed)
 
 
 class _CBCELossFrames(torch.autograd.Function):
@@ -73,20 +102,22 @@ class _CBCELossFrames(torch.autograd.Function):
     gradients in one buffer so that backward is a single scale."""
 
     @staticmethod
-    def forward(ctx, output, label, size_average):
+    def forward(ctx, output, label, size_average, backward_seed=None):
+        ctx.seed_ptr, ctx.seed_value = _seed_of(backward_seed)
         losses, grad = ops.cbce_loss_frames(output.contiguous().float(), label.contiguous().float(),
-                                            size_average=bool(size_average), want_grad=output.requires_grad)
+                                            size_average=bool(size_average), want_grad=output.requires_grad,
+                                            grad_scale=ctx.seed_value)
         ctx.grad = grad
         return losses
 
     @staticmethod
     def backward(ctx, g):
         if ctx.grad is None:
-            return None, None, None
-        return ctx.grad * g.reshape(-1, 1, 1, 1), None, None
+            return None, None, None, None
+        return _scaled(ctx, g), None, None, None
 
 
-def class_balanced_cross_entropy_loss_frames(output, label, size_average=True):
+def class_balanced_cross_entropy_loss_frames(output, label, size_average=True, backward_seed=None):
     """``class_balanced_cross_entropy_loss`` of each frame of a batch separately: a [N] tensor whose element i equals
     ``class_balanced_cross_entropy_loss(output[i:i+1], label[i:i+1], size_average)``.  Not in the reference; the
     online loop uses it when it runs several micro-batches of an accumulation cycle as one batched pass, where every
@@ -99,7 +130,7 @@ def class_balanced_cross_entropy_loss_frames(output, label, size_average=True):
     if tuple(label.shape) != tuple(output.shape):
         raise ValueError("class_balanced_cross_entropy_loss_frames: output {} vs label {}".format(
             tuple(output.shape), tuple(label.shape)))
-    return _CBCELossFrames.apply(output, label, size_average)
+    return _CBCELossFrames.apply(output, label, size_average, backward_seed)
 
 
 def crop_offsets(size, target):

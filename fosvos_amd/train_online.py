@@ -93,10 +93,10 @@ def _group_window() -> int:
         return 16
 
 
-def _losses_per_frame(fused, gts):
+def _losses_per_frame(fused, gts, backward_seed=None):
     """[k] per-frame losses of a batched pass; one fused op on the GPU, the reference's function per slice elsewhere."""
     if fused.is_cuda and class_balanced_cross_entropy_loss is _hip_cbce:
-        return class_balanced_cross_entropy_loss_frames(fused, gts, size_average=False)
+        return class_balanced_cross_entropy_loss_frames(fused, gts, size_average=False, backward_seed=backward_seed)
     return torch.stack([class_balanced_cross_entropy_loss(fused[i:i + 1], gts[i:i + 1], size_average=False)
                         for i in range(fused.shape[0])])
 
@@ -143,6 +143,8 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     late_params = [p for group in optimizer.param_groups for p in group['params'] if id(p) not in early_ids]
     early_prefixes = tuple(pre for b in early_buckets for pre in parallel.VGG_BUCKETS[flat.bucket_ids[b]])
 
+    # lab switch (A/B only): 0 = separate gradient memsets behind the optimizer step and an unannounced backward seed
+    fuse_small = os.environ.get('FOSVOS_LOOP_FUSE', '1') != '0'
     n_samples = len(dataloader)
     loss_tr = []
     counter_gradient = 0
@@ -238,11 +240,17 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
 
         outputs = net.forward(inputs)
 
+        # (the seed of the backward pass below is announced to the loss: its kernel writes the gradient times 1 / nAveGrad
+        # and the loss's own backward has nothing left to multiply)
+        seeded = fuse_small and outputs[-1].is_cuda and class_balanced_cross_entropy_loss is _hip_cbce
         if k == 1:
-            loss = class_balanced_cross_entropy_loss(outputs[-1], gts, size_average=False)
+            loss = (class_balanced_cross_entropy_loss(outputs[-1], gts, size_average=False,
+                                                      backward_seed=(inv_avg, 1.0 / avg_grad_every_n))
+                    if seeded else class_balanced_cross_entropy_loss(outputs[-1], gts, size_average=False))
             losses = loss.detach().reshape(1)
         else:
-            loss = _losses_per_frame(outputs[-1], gts)  # [k]; the sum over frames is taken by the backward seed
+            # [k]; the sum over frames is taken by the backward seed
+            loss = _losses_per_frame(outputs[-1], gts, (inv_avg_k, 1.0 / avg_grad_every_n) if seeded else None)
             losses = loss.detach()
         record_losses(group, losses)
 
@@ -279,13 +287,15 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
                         sync.wait_bucket(b)
                     else:
                         net.wait_grad_bucket(flat.bucket_ids[b])
-                optimizer.step(only=early_params, tag='early')
-                flat.zero(early_buckets)
+                optimizer.step(only=early_params, tag='early', zero_grad=fuse_small)  # (the step kernel zeroes what it read)
+                if not fuse_small:
+                    flat.zero(early_buckets)
                 net.prepack_weights(early_prefixes)
                 net.join_gradients()
                 sync.finish()
-                optimizer.step(only=late_params, tag='late')
-                flat.zero(late_buckets)
+                optimizer.step(only=late_params, tag='late', zero_grad=fuse_small)
+                if not fuse_small:
+                    flat.zero(late_buckets)
             else:
                 net.join_gradients()
                 sync.finish()  # the bucketed all-reduce begun right behind the cycle's last backward pass

@@ -273,10 +273,15 @@ int fosvos_cbce_loss_batch_counts(const float *logits, const float *label, int64
 /* ---- SGD with momentum, torch.optim.SGD semantics, many tensors per launch --------------------
  * For tensor t with n[t] elements: g = grad + wd[t]*p; buf = first_step ? g : momentum*buf + g;
  * p -= lr[t]*buf.  `table` is a DEVICE array of n_tensors fosvos_sgd_entry records.
+ * `first_step` is a flag word: bit 0 = first step (buf = g), bit 1 (FOSVOS_SGD_ZERO_GRAD) = every gradient is overwritten
+ * with zeros once it has been read - optimizer.step() + optimizer.zero_grad() (src/train_online.py:100-104) in one pass over
+ * the gradients instead of a step and a memset.
  * replaces: optim.SGD.step for the groups of src/util/network_provider.py:144-159 / 98-125. */
+#define FOSVOS_SGD_FIRST_STEP 1
+#define FOSVOS_SGD_ZERO_GRAD 2
 typedef struct fosvos_sgd_entry {
     float *param;
-    const float *grad;
+    const float *grad; /* written (zeroed) only under FOSVOS_SGD_ZERO_GRAD */
     float *momentum_buf;
     int64_t numel;
     float lr;

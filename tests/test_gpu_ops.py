@@ -547,7 +547,67 @@ def test_cbce_sizes(ops, shape):
     assert loss2.item() == loss.item()  # deterministic reduction
 
 
+def test_cbce_announced_backward_seed():
+    """The online loop announces the tensor it seeds the backward pass with (1 / nAveGrad): the loss kernel writes the
+    gradient already multiplied and the backward pass of THAT tensor launches nothing; any other incoming gradient still
+    gives the right answer.  Both the single-tensor loss and the per-frame loss of a batched pass."""
+    from layers import osvos_layers as L
+    x = gen(3, 1, 24, 36, seed=74).to(DEV)
+    y = (gen(3, 1, 24, 36, seed=75) > 0.3).float().to(DEV)
+    seed = torch.full((3,), 0.2, device=DEV)
+    one = torch.ones((), device=DEV) / 5
+
+    def run(fn, out_slice, seed_t, announce, incoming):
+        xi = x[out_slice].clone().requires_grad_(True)
+        loss = fn(xi, y[out_slice], size_average=False, backward_seed=(seed_t, 0.2) if announce else None)
+        loss.backward(incoming)
+        return xi.grad
+
+    hits0 = L.seed_hits
+    plain = run(L.class_balanced_cross_entropy_loss_frames, slice(0, 3), seed, False, seed)
+    fast = run(L.class_balanced_cross_entropy_loss_frames, slice(0, 3), seed, True, seed)
+    assert L.seed_hits == hits0 + 1
+    assert rel_err(fast.cpu(), plain.cpu()) < 1e-6            # (scale folded into the class weights in fp64: <= 1 ulp apart)
+    other = torch.tensor([0.5, 1.0, 0.25], device=DEV)
+    got = run(L.class_balanced_cross_entropy_loss_frames, slice(0, 3), seed, True, other)
+    want = run(L.class_balanced_cross_entropy_loss_frames, slice(0, 3), seed, False, other)
+    assert L.seed_hits == hits0 + 1 and rel_err(got.cpu(), want.cpu()) < 1e-6
+    plain1 = run(L.class_balanced_cross_entropy_loss, slice(0, 1), one, False, one)
+    fast1 = run(L.class_balanced_cross_entropy_loss, slice(0, 1), one, True, one)
+    assert L.seed_hits == hits0 + 2 and rel_err(fast1.cpu(), plain1.cpu()) < 1e-6
+    assert torch.equal(fast1, fast[0:1])                       # the batched pass's frame 0 == the frame alone
+
+
 # ------------------------------------------------------------------------------------------ SGD
+def test_fused_sgd_zero_grad_flag():
+    """step(zero_grad=True) = step() then zero_grad(set_to_none=False), in one pass over the gradients - also for a subset."""
+    from fosvos_hip.sgd import FusedSGD
+    g = torch.Generator().manual_seed(81)
+    shapes = [(64, 3, 3, 3), (5,), (33, 7)]
+    pa = [torch.randn(s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = FusedSGD(pa, lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    ob = FusedSGD(pb, lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    for step in range(3):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).to(DEV)
+            a.grad = gr.clone() if a.grad is None else a.grad.copy_(gr)
+            b.grad = gr.clone()
+        keep = [a.grad for a in pa]
+        if step == 1:  # a subset: the others keep their gradients
+            oa.step(only=pa[:2], tag="part", zero_grad=True)
+            ob.step(only=pb[:2], tag="part")
+            assert not pa[0].grad.any() and not pa[1].grad.any() and pa[2].grad.any()
+            oa.step(only=pa[2:], tag="rest", zero_grad=True)
+            ob.step(only=pb[2:], tag="rest")
+        else:
+            oa.step(zero_grad=True)
+            ob.step()
+        for a, b, k in zip(pa, pb, keep):
+            assert torch.equal(a.detach(), b.detach())
+            assert a.grad is k and not a.grad.any()            # same tensor, now zeros
+
+
 def test_fused_sgd_matches_torch():
     from fosvos_hip.sgd import FusedSGD
     shapes = [(64, 3, 3, 3), (64,), (128, 64, 3, 3), (1, 64, 1, 1), (1,), (7, 5)]
