@@ -136,6 +136,53 @@ def cpu_baseline(iters: int):
                       f"1x3x{H}x{W} fp32 (oracle/osvos_ref.py, torch {torch.__version__} CPU), {dt / iters * 1000:.0f} ms/iter"}
 
 
+def alone_rates(dev, n_frames, H, W):
+    """The conv MFMA kernels ALONE on the chip: every 3x3 layer shape of the backbone (conv1_2 .. conv5_3) at `n_frames`
+    frames per launch, one op at a time, HIP events on the launch stream; FLOP-weighted TFLOP/s of the forward, data-gradient
+    and weight-gradient launches.  What the kernels sustain when nothing shares the chip with them - the in-step durations
+    of `roofline.by_kernel` are those of kernels that overlap (two forward chains, data- and weight-gradient streams)."""
+    import torch
+    from fosvos_hip import ops
+    shapes = [(1, 64, 64, 1), (2, 64, 128, 1), (2, 128, 128, 1), (4, 128, 256, 1), (4, 256, 256, 2), (8, 256, 512, 1),
+              (8, 512, 512, 2), (16, 512, 512, 3)]  # (downscale, Ci, Co, layers of that shape)
+    g = torch.Generator(device=dev).manual_seed(7)
+    tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
+
+    def timeit(fn, reps=5):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    for ds, ci, co, count in shapes:
+        h, w = H, W
+        d = 1
+        while d < ds:  # ceil-mode pooling
+            h, w, d = (h + 1) // 2, (w + 1) // 2, d * 2
+        x = torch.randn(n_frames, h, w, ci, device=dev, generator=g).to(torch.bfloat16)
+        dy = torch.randn(n_frames, h, w, co, device=dev, generator=g).to(torch.bfloat16)
+        wt = torch.randn(co, ci, 3, 3, device=dev, generator=g) * (2.0 / (9 * ci)) ** 0.5
+        b = torch.zeros(co, device=dev)
+        wf, wd = ops.pack_conv3x3_weights(wt)
+        flop = 2.0 * n_frames * h * w * 9 * ci * co * count
+        for op, fn in (("fwd", lambda: ops.conv3x3_fwd(x, wf, b, ci, co, relu=True)),
+                       ("dgrad", lambda: ops.conv3x3_dgrad(dy, wd, ci, co, relu_src=x)),
+                       ("wgrad", lambda: ops.conv3x3_wgrad(x, dy, ci, co))):
+            tot[op][0] += flop
+            tot[op][1] += timeit(fn) * count
+        del x, dy
+    res = {op: round(f / t / 1e12, 1) for op, (f, t) in tot.items()}
+    all_f, all_t = sum(v[0] for v in tot.values()), sum(v[1] for v in tot.values())
+    return {"frames_per_launch": n_frames, "tflops": res, "family_tflops": round(all_f / all_t / 1e12, 1),
+            "family_frac": all_f / all_t / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            "note": "12 backbone layers (conv1_2..conv5_3), one op at a time, weight gradient incl. its slab reduction"}
+
+
 def offline_config(args, dev, make_frame, barrier):
     """BASELINE.json configs[2]: train_offline._train itself on resident batches of 16 synthetic 480x854 frames, five deeply
     supervised losses, avg_grad_every_n = 10 (src/train_offline.py:77-110).  One epoch = 10 iterations = one optimizer
@@ -412,23 +459,30 @@ def main():
         conv_ms = sum(a["ms"] for a in conv) / n_prof
         conv_calls = sum(a["launches"] for a in conv) / n_prof
         conv_flop = sum(a["flops"] for a in conv) / n_prof
-        achieved = conv_flop / (conv_ms * 1e-3) / 1e12
-        # HBM bytes per launch of the same kernel family from the committed PMC passes (rocprofv3 cannot run inside
-        # this process); null when no summary is present
-        traffic, traffic_note = None, "no profiles/*_pmc_traffic.json present"
+        fam_achieved = conv_flop / (conv_ms * 1e-3) / 1e12
+        # the dominant kernel: the MFMA kernel with the most time per step
+        dom_name, dom = max(((k, a) for k, a in prof.records.items() if k.startswith(CONV_KERNEL_PREFIXES)),
+                            key=lambda kv: kv[1]["ms"])
+        achieved = dom["flops"] / dom["ms"] / 1e9
+        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process); null when no
+        # summary is present or the kernel is not in it
+        traffic, fam_traffic, traffic_note = None, None, "no profiles/*_pmc_traffic.json present"
         try:
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
             if cands:
                 pm = json.load(open(cands[-1]))
-                traffic = pm["summary"]["conv_mfma_family"]["hbm_bytes_per_launch"]
-                traffic_note = (f"bytes/launch, conv MFMA family, from {os.path.relpath(cands[-1], ROOT)}: {pm['source']}; "
-                                f"{pm['corrections']}")
+                fam_traffic = pm["summary"]["conv_mfma_family"]["hbm_bytes_per_launch"]
+                for k, v in pm.get("per_kernel", {}).items():
+                    if k.endswith(dom_name):
+                        traffic = v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]
+                traffic_note = (f"HBM bytes/launch of this kernel (family: all conv MFMA kernels) from "
+                                f"{os.path.relpath(cands[-1], ROOT)}: {pm['source']}; {pm['corrections']}")
         except Exception as e:  # a malformed summary must not break the bench line
             traffic_note = f"could not read PMC summary: {e}"
         out["roofline"] = {
             "bound": "mfma",
-            "kernel": "conv3x3 MFMA family: k_conv3x3_igemm (forward + data gradient), k_wgrad3x3 / k_wgrad_first (weight gradient), bf16",
+            "kernel": dom_name + " (the MFMA kernel with the most time per step; bf16 operands, fp32 accumulate)",
             "achieved": achieved,
             "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s",
@@ -436,18 +490,27 @@ def main():
             "traffic": traffic,
             "traffic_note": traffic_note,
             "measured": f"HIP event pairs on each kernel's launch stream, {n_prof} steps of the shipped two-stream execution "
-                        f"right behind the timed region (kernels of the two streams overlap, as under rocprofv3)",
-            "launches_per_step": conv_calls,
-            "algorithmic_gflop_per_step": conv_flop / 1e9,
-            "avg_launch_us": conv_ms / conv_calls * 1000.0,
+                        f"right behind the timed region.  Kernels overlap, as under rocprofv3: the forward pass runs as two "
+                        f"chains of frames on the two streams, the backward pass as a data-gradient and a weight-gradient "
+                        f"stream, so a kernel's duration is that of a kernel sharing the chip; `alone` = the same kernels with "
+                        f"the chip to themselves, `step_wall_frac` = the step's FLOPs over its wall time",
+            "launches_per_step": dom["launches"] / n_prof,
+            "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
+            "avg_launch_us": dom["ms"] / dom["launches"] * 1000.0,
+            # all conv MFMA kernels together (k_conv3x3_igemm forward + data gradient, k_wgrad3x3 / k_wgrad_first): the
+            # figure `roofline.achieved` carried until round 3
+            "family": {"achieved": fam_achieved, "frac": fam_achieved / MFMA_BF16_PEAK_TFLOPS,
+                       "launches_per_step": conv_calls, "algorithmic_gflop_per_step": conv_flop / 1e9,
+                       "avg_launch_us": conv_ms / conv_calls * 1000.0, "traffic": fam_traffic},
             "device_ms_per_step_all_kernels": sum(a["ms"] for a in prof.records.values()) / n_prof,
-            # the same FLOPs over the WALL time of a step of the timed region (everything included: the two streams overlap,
+            # the same FLOPs over the WALL time of a step of the timed region (everything included: the streams overlap,
             # so the kernel durations above add up to more than the step; the non-MFMA kernels, launch gaps and the optimizer
             # step are in it too): what the whole step sustains, next to what its kernels sustain while they run
             "step_wall_tflops": conv_flop / 1e12 / (elapsed / args.steps),
             "step_wall_frac": conv_flop / 1e12 / (elapsed / args.steps) / MFMA_BF16_PEAK_TFLOPS,
             "by_kernel": by_kernel,
         }
+        out["roofline"]["alone"] = alone_rates(dev, AVG_GRAD_EVERY_N, H, W)
     if rank == 0 and not args.no_infer:
         # f1: the reference's eval_speeds protocol on 480x854 frames, all five logit maps computed
         from util import experiment_helper, io_helper

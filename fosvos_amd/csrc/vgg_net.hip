@@ -63,15 +63,24 @@ Arena make_arena(int N, int H, int W) {
     a.wsa_conv_bytes[0] = up256(fosvos_conv3x3_first_wgrad_workspace_bytes(N, H, W, 64));
     for (int c = 1; c < kNConv; ++c) {
         const int s = kStageOf[c];
-        a.wsa_conv_bytes[c] = up256(fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kCin[c], kCout[c]));
+        a.wsa_conv_bytes[c] = fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kCin[c], kCout[c]);
+        // (in the forward pass the second chain of a split batch uses it as its split-K workspace)
+        if (N >= 2)
+            a.wsa_conv_bytes[c] = std::max(a.wsa_conv_bytes[c],
+                                           fosvos_conv3x3_workspace_bytes(N - (N + 1) / 2, a.sh[s], a.sw[s], kCin[c], kCout[c]));
+        a.wsa_conv_bytes[c] = up256(a.wsa_conv_bytes[c]);
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kCin[c], kCout[c]));   // fwd split-K
+        if (N >= 2)  // ... of the first chain of a split batch (fewer frames can mean MORE splits)
+            ws = std::max(ws, fosvos_conv3x3_workspace_bytes((N + 1) / 2, a.sh[s], a.sw[s], kCin[c], kCout[c]));
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kCout[c], kCin[c]));   // dgrad split-K
     }
     for (int s = 1; s < 5; ++s) {
         // (also the split-K workspace of the side layer's FORWARD conv when that runs on the auxiliary stream)
-        a.wsa_side_bytes[s - 1] = up256(std::max(fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16),
-                                                 fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16)));
+        a.wsa_side_bytes[s - 1] = up256(std::max({fosvos_conv3x3_wgrad_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16),
+                                                  fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16),
+                                                  N >= 2 ? fosvos_conv3x3_workspace_bytes(N - (N + 1) / 2, a.sh[s], a.sw[s], kStageCh[s], 16) : (size_t)0}));
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], kStageCh[s], 16));
+        if (N >= 2) ws = std::max(ws, fosvos_conv3x3_workspace_bytes((N + 1) / 2, a.sh[s], a.sw[s], kStageCh[s], 16));
         ws = std::max(ws, fosvos_conv3x3_workspace_bytes(N, a.sh[s], a.sw[s], 16, kStageCh[s]));
     }
     a.ws_bytes = up256(ws);
@@ -128,6 +137,64 @@ int forward_impl(hipEvent_t *ev, const fosvos_vgg_weights *w, const float *frame
     const bool par = ev != nullptr && aux_stream != nullptr && aux_stream != stream;
     hipStream_t sa = par ? (hipStream_t)aux_stream : sm;
     if (par) FOSVOS_ENTER(device);
+    // The frames of a batched pass run as TWO independent chains, the first ceil(N/2) on `stream`, the rest on the auxiliary
+    // stream: the launches of one chain fill the partial last round of the other's (five 480x854 frames: conv3 is 4.1 rounds
+    // of 512 workgroups, conv4 2.2) and what one chain's workgroups spend outside their chunk loops.  +1.0 % on the step.
+    // Without an auxiliary stream the same two chains run one after the other (the arithmetic of a pass - tile plans, split-K -
+    // does not depend on how it is scheduled).  FOSVOS_FWD_SPLIT=0 (lab switch): one chain of N frames.
+    static const bool split_on = !(getenv("FOSVOS_FWD_SPLIT") && atoi(getenv("FOSVOS_FWD_SPLIT")) == 0);
+    if (split_on && N >= 2) {
+        const int na = (N + 1) / 2;
+        if (par) {
+            FOSVOS_HIP_CHECK(hipEventRecord(ev[14], sm));
+            FOSVOS_HIP_CHECK(hipStreamWaitEvent(sa, ev[14], 0));
+        }
+        for (int half = 0; half < 2; ++half) {
+            const int f0 = half ? na : 0, nf = half ? N - na : na;
+            hipStream_t st = half ? sa : sm;
+            const uint16_t *xh = nullptr;
+            for (int c = 0; c < kNConv; ++c) {
+                const int s = kStageOf[c];
+                const size_t px = (size_t)a.sh[s] * a.sw[s];
+                uint16_t *yc = act(c) + (size_t)f0 * px * kCout[c];
+                // the second chain's split-K workspace: the layer's own weight-gradient workspace (idle in the forward pass)
+                void *wsc = half ? base + a.wsa_conv[c] : ws;
+                const size_t wsn = half ? a.wsa_conv_bytes[c] : a.ws_bytes;
+                if (c == 0) {
+                    FOSVOS_TRY(fosvos_conv3x3_first_fwd(frame + (size_t)f0 * 3 * H * W, w->conv_w[0], w->conv_b[0], yc, nf, H, W,
+                                                        kCout[0], device, st));
+                } else {
+                    if (c == kFirstOfStage[s]) {
+                        const size_t ppx = (size_t)a.sh[s] * a.sw[s];
+                        xh = reinterpret_cast<uint16_t *>(base + a.pooled[s - 1]) + (size_t)f0 * ppx * kCin[c];
+                    }
+                    FOSVOS_REQUIRE(wsn >= fosvos_conv3x3_workspace_bytes(nf, a.sh[s], a.sw[s], kCin[c], kCout[c]),
+                                   FOSVOS_E_WORKSPACE, "vgg_forward: split-K workspace of the second chain");
+                    if (c == kLastOfStage[s] && s < 4) {
+                        const size_t qpx = (size_t)a.sh[s + 1] * a.sw[s + 1];
+                        FOSVOS_TRY(fosvos_conv3x3_fwd_pool(xh, w->conv_wf[c], w->conv_b[c], yc,
+                                                           reinterpret_cast<uint16_t *>(base + a.pooled[s]) + (size_t)f0 * qpx * kCout[c],
+                                                           nf, a.sh[s], a.sw[s], kCin[c], kCout[c], FOSVOS_CONV_RELU, wsc, wsn,
+                                                           device, st));
+                    } else {
+                        FOSVOS_TRY(fosvos_conv3x3_fwd(xh, w->conv_wf[c], w->conv_b[c], yc, nf, a.sh[s], a.sw[s], kCin[c],
+                                                      kCout[c], FOSVOS_CONV_RELU, wsc, wsn, device, st));
+                    }
+                }
+                xh = yc;
+                if (s > 0 && c == kLastOfStage[s]) {
+                    float *so = reinterpret_cast<float *>(base + a.side[s - 1]) + (size_t)f0 * px * 16;
+                    FOSVOS_TRY(fosvos_conv3x3_fwd(xh, w->side_wf[s - 1], w->side_b[s - 1], so, nf, a.sh[s], a.sw[s], kStageCh[s],
+                                                  16, FOSVOS_CONV_OUT_F32, half ? base + a.wsa_side[s - 1] : ws,
+                                                  half ? a.wsa_side_bytes[s - 1] : a.ws_bytes, device, st));
+                }
+            }
+        }
+        if (par) {
+            FOSVOS_HIP_CHECK(hipEventRecord(ev[13], sa));
+            FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[13], 0));
+        }
+    } else {
     const uint16_t *x = nullptr;
     for (int c = 0; c < kNConv; ++c) {
         const int s = kStageOf[c];
@@ -164,6 +231,7 @@ int forward_impl(hipEvent_t *ev, const fosvos_vgg_weights *w, const float *frame
     if (par) {  // join: the head reads the four side maps
         FOSVOS_HIP_CHECK(hipEventRecord(ev[13], sa));
         FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[13], 0));
+    }
     }
     const float *side[4];
     int hs[4], wsz[4];
