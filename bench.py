@@ -74,6 +74,9 @@ def parse():
                     help="N > 1: which mapping(s) to time (both = dp, dp_strict and replicas); `value` is dp unless only "
                          "another one is asked for")
     ap.add_argument("--no-variants", action="store_true", help="skip the cold / group1 / mixed_scales / offline objects")
+    ap.add_argument("--no-alone", action="store_true",
+                    help="skip roofline.alone (the conv kernels one at a time): its launches would sit in a rocprofv3 summary "
+                         "of this command beside the in-step ones")
     ap.add_argument("--offline-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -510,7 +513,8 @@ def main():
             "step_wall_frac": conv_flop / 1e12 / (elapsed / args.steps) / MFMA_BF16_PEAK_TFLOPS,
             "by_kernel": by_kernel,
         }
-        out["roofline"]["alone"] = alone_rates(dev, AVG_GRAD_EVERY_N, H, W)
+        if not args.no_alone:
+            out["roofline"]["alone"] = alone_rates(dev, AVG_GRAD_EVERY_N, H, W)
     if rank == 0 and not args.no_infer:
         # f1: the reference's eval_speeds protocol on 480x854 frames, all five logit maps computed
         from util import experiment_helper, io_helper

@@ -18,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 # the profiled runs skip bench.py's device wake-up steps: the step counts in the summaries stay 80 (10 + 50 + 20) and 25 (5 + 20)
 export FOSVOS_BENCH_PRECONDITION=0
 echo "== kernel stats"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-infer --no-variants > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-infer --no-variants --no-alone > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
 echo "== pmc traffic"
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-infer --no-roofline --no-variants > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || exit 1
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-infer --no-roofline --no-variants > $OUT/pmc_write.json 2> $OUT/pmc_write.err || exit 1
