@@ -463,9 +463,13 @@ def main():
         conv_calls = sum(a["launches"] for a in conv) / n_prof
         conv_flop = sum(a["flops"] for a in conv) / n_prof
         fam_achieved = conv_flop / (conv_ms * 1e-3) / 1e12
-        # the dominant kernel: the MFMA kernel with the most time per step
-        dom_name, dom = max(((k, a) for k, a in prof.records.items() if k.startswith(CONV_KERNEL_PREFIXES)),
-                            key=lambda kv: kv[1]["ms"])
+        # the dominant kernel: the MFMA kernel template (all its instantiations) with the most time per step
+        groups = {}
+        for k, a in prof.records.items():
+            if k.startswith(CONV_KERNEL_PREFIXES):
+                g = groups.setdefault(k.split("<")[0], {"ms": 0.0, "flops": 0.0, "launches": 0, "names": []})
+                g["ms"] += a["ms"]; g["flops"] += a["flops"]; g["launches"] += a["launches"]; g["names"].append(k)
+        dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
         achieved = dom["flops"] / dom["ms"] / 1e9
         # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process); null when no
         # summary is present or the kernel is not in it
@@ -476,16 +480,20 @@ def main():
             if cands:
                 pm = json.load(open(cands[-1]))
                 fam_traffic = pm["summary"]["conv_mfma_family"]["hbm_bytes_per_launch"]
+                tb, tl = 0.0, 0
                 for k, v in pm.get("per_kernel", {}).items():
-                    if k.endswith(dom_name):
-                        traffic = v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]
+                    if any(k.endswith(n) for n in dom["names"]):
+                        tb += (v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]) * v["launches"]
+                        tl += v["launches"]
+                traffic = tb / tl if tl else None
                 traffic_note = (f"HBM bytes/launch of this kernel (family: all conv MFMA kernels) from "
                                 f"{os.path.relpath(cands[-1], ROOT)}: {pm['source']}; {pm['corrections']}")
         except Exception as e:  # a malformed summary must not break the bench line
             traffic_note = f"could not read PMC summary: {e}"
         out["roofline"] = {
             "bound": "mfma",
-            "kernel": dom_name + " (the MFMA kernel with the most time per step; bf16 operands, fp32 accumulate)",
+            "kernel": dom_name + " (the MFMA kernel template with the most time per step, all its instantiations: "
+                      + ", ".join(sorted(n[len(dom_name):] for n in dom["names"])) + "; bf16 operands, fp32 accumulate)",
             "achieved": achieved,
             "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s",
