@@ -512,7 +512,9 @@ def test_shipped_offline_train_vs_golden(golden):
 
 def test_native_loop_equals_per_op_engine():
     """The native layer loop (csrc/vgg_net.hip, what ships) and the per-op Python engine (what per-kernel event timing
-    brackets) issue the same kernels with the same launch parameters: logits and every gradient bit for bit."""
+    brackets) issue the same kernels with the same per-frame arithmetic: logits and every gradient bit for bit.  (The native
+    forward pass runs the two frames as two chains of one; a frame's result does not depend on its batch as long as the
+    plan's K split is the same, which it is at this size.)"""
     from fosvos_hip import engine
     from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
     x, gt = O.synthetic_frame(2, 61, 107, seed=51)
