@@ -442,12 +442,15 @@ typedef struct fosvos_vgg_grads {
 } fosvos_vgg_grads;
 
 size_t fosvos_vgg_arena_bytes(int N, int H, int W);
-/* fused: [N,1,H,W] fp32; side_out: four [N,1,H,W] fp32 buffers or NULL.  The arena keeps what backward needs. */
+/* fused: [N,1,H,W] fp32; side_out: four [N,1,H,W] fp32 buffers or NULL.  The arena keeps what backward needs.
+ * A batch (N >= 2) runs as two chains of ceil(N/2) and floor(N/2) frames - each layer is launched once per chain - so
+ * that a frame's arithmetic (tile plan, K split) is the same whether or not a second stream is there to run the chains
+ * side by side (fosvos_vgg_forward_streams). */
 int fosvos_vgg_forward(const fosvos_vgg_weights *w, const float *frame, int N, int H, int W, void *arena,
                        size_t arena_bytes, float *fused, float *const side_out[4], int device, void *stream);
-/* The same pass with a second stream of the same device (or NULL = fosvos_vgg_forward): the four side_prep convs
- * (16 output channels, memory-bound) are issued on aux_stream beside the next stage's backbone convs; `stream` waits for
- * them (events of `ctx`, whose device the call runs on) in front of the head, so the caller sees single-stream
+/* The same pass with a second stream of the same device (or NULL = fosvos_vgg_forward): the second chain of frames runs on
+ * aux_stream beside the first (one frame: only its four side_prep convs, beside the next stage's backbone convs); `stream`
+ * waits for it (events of `ctx`, whose device the call runs on) in front of the head, so the caller sees single-stream
  * semantics on `stream`.  Results are bit-identical to fosvos_vgg_forward. */
 int fosvos_vgg_forward_streams(fosvos_ctx *ctx, const fosvos_vgg_weights *w, const float *frame, int N, int H, int W,
                                void *arena, size_t arena_bytes, float *fused, float *const side_out[4], void *stream,
