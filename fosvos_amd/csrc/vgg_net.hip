@@ -190,10 +190,31 @@ int forward_impl(hipEvent_t *ev, const fosvos_vgg_weights *w, const float *frame
                 }
             }
         }
+        // each chain runs the head for its own frames (the head is per frame), so the first chain's head runs beside the
+        // second chain's last convs instead of behind them
+        static const bool head_per_chain = !(getenv("FOSVOS_HEAD_PER_CHAIN") && atoi(getenv("FOSVOS_HEAD_PER_CHAIN")) == 0);
+        if (head_per_chain) {
+            for (int half = 0; half < 2; ++half) {
+                const int f0 = half ? na : 0, nf = half ? N - na : na;
+                const float *sideh[4];
+                float *soh[4] = {nullptr, nullptr, nullptr, nullptr};
+                int hsh[4], wsh[4];
+                for (int i = 0; i < 4; ++i) {
+                    hsh[i] = a.sh[i + 1];
+                    wsh[i] = a.sw[i + 1];
+                    sideh[i] = reinterpret_cast<const float *>(base + a.side[i]) + (size_t)f0 * hsh[i] * wsh[i] * 16;
+                    if (side_out && side_out[i]) soh[i] = side_out[i] + (size_t)f0 * H * W;
+                }
+                FOSVOS_TRY(fosvos_head_fwd(sideh, hsh, wsh, w->filt, w->filt1, w->dsn_w, w->dsn_b, w->fuse_w, w->fuse_b,
+                                           fused + (size_t)f0 * H * W, (side_out && side_out[0]) ? soh : nullptr, nf, H, W, device,
+                                           half ? sa : sm));
+            }
+        }
         if (par) {
             FOSVOS_HIP_CHECK(hipEventRecord(ev[13], sa));
             FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[13], 0));
         }
+        if (head_per_chain) return FOSVOS_OK;
     } else {
     const uint16_t *x = nullptr;
     for (int c = 0; c < kNConv; ++c) {
