@@ -67,6 +67,34 @@ def test_module_surface():
         net(torch.zeros(1, 3, 8, 8))  # CPU tensor: no fallback
 
 
+@pytest.mark.parametrize("n", [2, 3, 5])
+def test_batched_forward_equals_frame_by_frame(n):
+    """A batch runs as two chains of frames (ceil(n/2) on the main stream, the rest on the auxiliary one, each with its own
+    head launch): every frame's five logit maps and, after one backward pass over all five losses, the weight gradients equal
+    what the frames give one by one - the chains' offsets into the arena, the side maps and the five output maps, n odd and
+    even.  Logits within 1e-2 of the largest (a frame's K split may differ with the chain's size: bf16 rounding of fp32 sums),
+    gradients against the sum of the per-frame gradients."""
+    from layers.osvos_layers import class_balanced_cross_entropy_loss as cbce
+    frames = [O.synthetic_frame(1, 49, 83, seed=300 + i) for i in range(n)]
+    x = torch.cat([f[0] for f in frames]).to(DEV)
+    gt = torch.cat([f[1] for f in frames]).to(DEV)
+    net, _ = make_net(31)
+    outs = net(x)
+    assert len(outs) == 5 and all(tuple(o.shape) == (n, 1, 49, 83) for o in outs)
+    sum(cbce(o[i:i + 1], gt[i:i + 1], size_average=False) for o in outs for i in range(n)).backward()
+    g_batch = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    net.zero_grad(set_to_none=True)
+    for i in range(n):
+        oi = net(x[i:i + 1])
+        for a, b in zip(oi, outs):
+            assert rel_to_max(a.detach(), b[i:i + 1].detach()) <= 1e-2, (n, i)  # (measured <= 5.1e-3; a wrong offset is an O(1) error)
+        sum(cbce(o, gt[i:i + 1], size_average=False) for o in oi).backward()
+    for k, g in g_batch.items():
+        one = dict(net.named_parameters())[k].grad
+        err = (g - one).norm().item() / max(one.norm().item(), 1e-30)
+        assert err <= GRAD_REL_L2, (n, k, err)
+
+
 @pytest.mark.parametrize("tag", ["s", "r"])
 def test_forward_vs_reference_golden(golden, tag):
     k = golden("net.npz")
