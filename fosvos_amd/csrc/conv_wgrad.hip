@@ -34,7 +34,7 @@ struct WgArgs {
     float *bias_part;    // [S * n_ci][Cor] column sums of dy per split and ci block (each sums its share of the tiles), or null
     int N, H, W, Ci, Cy, Cor;
     int tiles_x, tiles_y, n_tiles, tiles_per_split;
-    int lab;  // timing-only switch (FOSVOS_WGRAD_LAB; wrong results): 1 no slab store
+    int lab;  // timing-only switch of lab builds (-DFOSVOS_LAB_BUILD, FOSVOS_WGRAD_LAB; wrong results): 1 no slab store; always 0 in the shipped library
     int S, n_ci, n_co, xcd_order;  // 1-D grid of S * n_ci * n_co workgroups, decoded in the kernel (see there)
 };
 
@@ -578,8 +578,12 @@ int fosvos::wgrad_impl(const uint16_t *x, const uint16_t *dy, float *dw, float *
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles; a.tiles_per_split = p.tps;
     a.S = p.S; a.n_ci = Ci / 64; a.n_co = p.side ? 1 : p.Cor / 64;
     {
+#ifdef FOSVOS_LAB_BUILD  // timing experiments only (never in the shipped library: the switch drops the slab stores)
         static const int lab = getenv("FOSVOS_WGRAD_LAB") ? atoi(getenv("FOSVOS_WGRAD_LAB")) : 0;
         a.lab = lab;
+#else
+        a.lab = 0;
+#endif
         const char *e = getenv("FOSVOS_WGRAD_XCD");  // lab switch (read per call: one process can A/B): 0 = plain workgroup order
         a.xcd_order = !(e && atoi(e) == 0);
     }
