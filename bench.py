@@ -279,6 +279,10 @@ def main():
     dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    # the library's two auxiliary streams, created before anything else in this process creates streams (the process group,
+    # RCCL): which hardware queue a stream gets depends on creation order, and two streams on one queue do not overlap
+    from fosvos_hip import engine as _engine
+    _engine.shared_stream(dev_index, "pass")
     distinct = 1
     if world > 1:
         dist.init_process_group(backend=backend)
@@ -371,7 +375,9 @@ def main():
     modes = ["single"] if world == 1 else (["dp", "dp_strict", "replicas"] if args.mode == "both" else [args.mode])
     results = {}
     cold = None
-    if world == 1 and not args.no_variants:
+    only = os.environ.get("FOSVOS_BENCH_ONLY")  # lab: comma-separated subset of cold,group1,mixed_scales,offline
+    want = (lambda name: only is None or name in only.split(","))
+    if world == 1 and not args.no_variants and want("cold"):
         # FIRST, on the device as the start-up of the process left it: W warm-up steps, K timed steps, no preconditioning
         cold = timed("cold", precondition=0)[0]
     for m in modes:
@@ -424,11 +430,12 @@ def main():
     if cold is not None:
         out["cold"] = {"value": args.steps / cold, "unit": "frames/s", "ms_per_step": cold / args.steps * 1000.0,
                        "note": f"the same {args.steps} steps behind {args.warmup} warm-up steps only, timed first (no preconditioning)"}
-    if world == 1 and not args.no_variants:
+    if world == 1 and not args.no_variants and want("group1"):
         # one frame per pass: the reference's own order, and the worst case of the shape bucketing
         e = timed("group1", env={"FOSVOS_MICROBATCH_GROUP": "1"})[0]
         out["group1"] = {"value": args.steps / e, "unit": "frames/s", "ms_per_step": e / args.steps * 1000.0,
                          "note": "FOSVOS_MICROBATCH_GROUP=1: every micro-batch its own forward / backward pass"}
+    if world == 1 and not args.no_variants and want("mixed_scales"):
         # the reference's augmentation: a random scale per iteration, fixed seed; 20 frames per epoch
         import random
         rng = random.Random(1234)
@@ -441,7 +448,17 @@ def main():
         saved_steps, saved_warm = args.steps, args.warmup
         args.steps, args.warmup = 100, 20
         try:
+            if os.environ.get("FOSVOS_BENCH_DEBUG"):
+                st = torch.cuda.memory_stats()
+                print("before mixed: reserved %.1f GB allocated %.1f GB device_allocs %d retries %d" % (
+                    st["reserved_bytes.all.current"] / 2**30, st["allocated_bytes.all.current"] / 2**30,
+                    st["num_device_alloc"], st["num_alloc_retries"]), file=sys.stderr)
             e = timed("mixed", precondition=40, loader=mixed)[0]
+            if os.environ.get("FOSVOS_BENCH_DEBUG"):
+                st = torch.cuda.memory_stats()
+                print("after mixed: reserved %.1f GB allocated %.1f GB device_allocs %d device_frees %d retries %d host_lead %s" % (
+                    st["reserved_bytes.all.current"] / 2**30, st["allocated_bytes.all.current"] / 2**30,
+                    st["num_device_alloc"], st["num_device_free"], st["num_alloc_retries"], host_lead.get("mixed")), file=sys.stderr)
         finally:
             args.steps, args.warmup = saved_steps, saved_warm
         px = sum(b["image"].shape[2] * b["image"].shape[3] for b in mixed) / len(mixed)
@@ -451,6 +468,7 @@ def main():
                                "note": "frames drawn from {1.0, 0.8, 0.5} x 480x854 (seed 1234, 20 per epoch), bucketed by "
                                        "shape inside each accumulation cycle of 5 (src/dataloaders/custom_transforms.py:63-76)"}
         del mixed
+    if world == 1 and not args.no_variants and want("offline"):
         out["offline"] = offline_config(args, dev, make_frame, barrier)
 
     if rank == 0 and not args.no_roofline:

@@ -284,6 +284,25 @@ USE_NATIVE_LOOP = os.environ.get("FOSVOS_PY_ENGINE", "0") != "1"  # debugging sw
 _CONV_NAMES = [(wn, bn) for (_, _, _, _, wn, bn) in CONVS]
 
 
+# The auxiliary streams of this process, one per device and role, created once and shared by every model: which hardware
+# queue a HIP stream lands on depends on how many streams the process has created before it (ROCclr deals its - by default
+# four - queues round-robin), and two streams on one hardware queue do not overlap at all.  A fresh stream per model (or per
+# training call) therefore made the two-stream passes fast or slow by creation order (seen: 1290 vs 950 frames/s for the
+# same loop, depending on what ran earlier in the process).  Fixed streams make the mapping the same for every model.
+_SHARED_STREAMS: Dict[Tuple[int, str], "torch.cuda.Stream"] = {}
+
+
+def shared_stream(device_index: int, role: str) -> "torch.cuda.Stream":
+    key = (device_index, role)
+    st = _SHARED_STREAMS.get(key)
+    if st is None:
+        order = ("aux", "pass", "comm")  # creation order is part of the contract: the weight-gradient stream first
+        for earlier in order[:order.index(role)] if role in order else ():
+            shared_stream(device_index, earlier)
+        st = _SHARED_STREAMS[key] = torch.cuda.Stream(device=device_index)
+    return st
+
+
 class ArenaPool:
     """Activation/gradient/workspace arenas, one size per (N, H, W); the library never allocates."""
 
@@ -300,8 +319,7 @@ class ArenaPool:
             return 0
         st = self._aux.get(device_index)
         if st is None:
-            st = torch.cuda.Stream(device=device_index)
-            self._aux[device_index] = st
+            st = self._aux[device_index] = shared_stream(device_index, "aux")
         return st.cuda_stream
 
     def ctx(self, device_index: int):
@@ -333,7 +351,7 @@ class ArenaPool:
     def give(self, n: int, h: int, w: int, arena: torch.Tensor) -> None:
         key = (n, h, w, arena.device.index)
         free = self._free.setdefault(key, [])
-        if len(free) < 2:
+        if len(free) < 6:  # (a cycle of single-frame passes holds one arena per pass until its join)
             free.append(arena)
 
 
@@ -394,7 +412,10 @@ def native_forward(P, packs, pool: ArenaPool, x: torch.Tensor, with_side_out: bo
     # batched passes: the side_prep convs ride on the auxiliary stream beside the next stage's backbone convs (+0.4 % on the
     # five-frame training pass; FOSVOS_FWD_AUX=0: one stream).  A single frame stays on one stream: its kernels are too
     # short for the four event pairs to pay (inference protocol: 0.586 vs 0.564 ms per frame).
-    aux = pool.aux_stream(idx) if N >= 2 and os.environ.get("FOSVOS_FWD_AUX", "1") != "0" else 0
+    # (forward_one_stream: the online loop sets it while it runs the passes of a cycle on two alternating streams - the
+    # auxiliary stream is then busy with the previous pass's weight gradients, and the second chain would queue behind them)
+    aux = (pool.aux_stream(idx) if N >= 2 and os.environ.get("FOSVOS_FWD_AUX", "1") != "0"
+           and not getattr(packs, "forward_one_stream", False) else 0)
     if aux:
         check(lib().fosvos_vgg_forward_streams(pool.ctx(idx), ctypes.byref(w), x.data_ptr(), N, H, W, ap, an, fused.data_ptr(),
                                                so, torch.cuda.current_stream(idx).cuda_stream, aux), "vgg_forward_streams")

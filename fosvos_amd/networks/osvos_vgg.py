@@ -100,6 +100,16 @@ class OSVOS_VGG(nn.Module):
         self._packs.defer_wgrad_join = bool(value)
 
     @property
+    def forward_one_stream(self):
+        return getattr(self._packs, "forward_one_stream", False)
+
+    @forward_one_stream.setter
+    def forward_one_stream(self, value):
+        """True: a batched forward pass keeps both of its chains of frames on the caller's stream (the online loop sets it
+        while the passes of a cycle alternate between two streams of their own)."""
+        self._packs.forward_one_stream = bool(value)
+
+    @property
     def publish_grad_buckets(self):
         return getattr(self._packs, "publish_grad_buckets", False)
 

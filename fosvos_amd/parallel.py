@@ -251,7 +251,9 @@ class GradSync:
         # the bucket events exist only where the native backward pass recorded them (not under FOSVOS_PY_ENGINE=1)
         if self.flat.flat.is_cuda and hasattr(net, "wait_grad_bucket") and getattr(net, "publishes_grad_buckets", True):
             if self._comm is None:
-                self._comm = torch.cuda.Stream(device=self.flat.flat.device)
+                from fosvos_hip import engine  # one communication stream per device and process (engine.shared_stream)
+                d = self.flat.flat.device
+                self._comm = engine.shared_stream(d.index if d.index is not None else torch.cuda.current_device(), "comm")
             main = torch.cuda.current_stream(self.flat.flat.device)
             comm = self._comm
 

@@ -145,6 +145,22 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
 
     # lab switch (A/B only): 0 = separate gradient memsets behind the optimizer step and an unannounced backward seed
     fuse_small = os.environ.get('FOSVOS_LOOP_FUSE', '1') != '0'
+    # A cycle whose micro-batches cannot run as ONE batched pass (frames of different sizes - the reference's augmentation
+    # draws a new scale per iteration - or FOSVOS_MICROBATCH_GROUP < nAveGrad) runs its passes on two alternating streams:
+    # the weights do not change inside a cycle and every pass has its own arena, so the forward pass of one micro-batch may
+    # run beside the backward pass of the previous one (their weight-gradient kernels share one stream and stay in order, so
+    # the accumulation into the gradients does too).  FOSVOS_PASS_STREAMS=0: one stream.
+    pass_streams = None
+    if flat.flat.is_cuda:  # (both auxiliary streams exist from here on, in a fixed creation order: see engine.shared_stream)
+        from fosvos_hip import engine as _engine0
+        _engine0.shared_stream(flat.flat.device.index if flat.flat.device.index is not None else torch.cuda.current_device(),
+                               "pass")
+    if (flat.flat.is_cuda and hasattr(net, 'join_gradients') and getattr(net, 'defer_wgrad_join', False)
+            and os.environ.get('FOSVOS_PASS_STREAMS', '1') != '0'):
+        from fosvos_hip import engine as _engine
+        _dev = flat.flat.device
+        pass_streams = [None, _engine.shared_stream(_dev.index if _dev.index is not None else torch.cuda.current_device(),
+                                                    "pass")]  # None = the caller's stream
     n_samples = len(dataloader)
     loss_tr = []
     counter_gradient = 0
@@ -222,7 +238,9 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     def is_snapshot_epoch(epoch: int) -> bool:
         return (epoch % snapshot_every_n) == snapshot_every_n - 1
 
-    def run_group(group) -> None:
+    side_stream_used = [False]  # a pass of the current cycle ran on pass_streams[1]: the optimizer step waits for it
+
+    def run_group(group, stream=None) -> None:
         """One forward / loss / backward pass over the micro-batches of `group` (iterations of the reference's loop with
         the same frame size, inside one accumulation cycle; consecutive or not - see run_window).  The weights do not change inside a cycle, so running k
         iterations as one batch of k frames leaves every frame's logits, loss (the class weights are still counted per
@@ -231,6 +249,18 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         split-K, fewer launch gaps) and one set of weight-gradient partial slabs per group instead of per frame."""
         nonlocal counter_gradient, n_iters
         k = len(group)
+        if stream is not None:
+            side_stream_used[0] = True
+            with torch.cuda.stream(stream):
+                run_pass(group, k)
+        else:
+            run_pass(group, k)
+        counter_gradient += k
+        n_iters += k
+        close_cycle_if_due()
+
+    def run_pass(group, k) -> None:
+        """Forward, loss and backward pass of one group, on the current stream."""
         if k == 1:
             inputs, gts = group[0][2]['image'], group[0][2]['gt']
         else:
@@ -270,9 +300,18 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             sync.begin()
         # (the reference also sums loss.item() into a per-epoch tensorboard scalar, src/train_online.py:94-104: one
         # device sync per frame; the per-pass asynchronous copy above carries the same information without it)
-        counter_gradient += k
-        n_iters += k
 
+    def wait_side_stream() -> None:
+        """The caller's stream waits for the passes of this cycle that ran on the second pass stream.  (The EARLY part of a
+        split optimizer step does not need this: the weight-gradient kernels of all passes share one stream, so the bucket
+        events of the cycle's last pass also say that every earlier pass is done with the stages they cover.)"""
+        if side_stream_used[0]:
+            torch.cuda.current_stream(device).wait_stream(pass_streams[1])
+            side_stream_used[0] = False
+
+    def close_cycle_if_due() -> None:
+        """The optimizer step behind the cycle's last pass, on the caller's stream."""
+        nonlocal counter_gradient
         if counter_gradient % local_accum == 0:
             if split_step:
                 # Stages 5-3 hold 97 % of the parameters and their gradients are final well before the backward pass ends.
@@ -291,12 +330,14 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
                 if not fuse_small:
                     flat.zero(early_buckets)
                 net.prepack_weights(early_prefixes)
+                wait_side_stream()
                 net.join_gradients()
                 sync.finish()
                 optimizer.step(only=late_params, tag='late', zero_grad=fuse_small)
                 if not fuse_small:
                     flat.zero(late_buckets)
             else:
+                wait_side_stream()
                 net.join_gradients()
                 sync.finish()  # the bucketed all-reduce begun right behind the cycle's last backward pass
                 optimizer.step()
@@ -314,8 +355,19 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             shape = tuple(item[2]['image'].shape)
             buckets.setdefault(shape if shape[0] == 1 else ('batch', id(item)), []).append(item)
         groups = [items[i:i + max_group] for items in buckets.values() for i in range(0, len(items), max_group)]
-        for group in groups:
-            run_group(group)
+        # (measured at 480x854, passes of 1 / 2 / 3+2 frames: +9.4 % / +2.0 % / -2.6 % - a pass of three or more frames does
+        # better with its two forward chains side by side, which needs the auxiliary stream the previous pass's weight
+        # gradients would still occupy)
+        multi = pass_streams is not None and world == 1 and len(groups) > 1 and max(len(g) for g in groups) <= 2
+        if multi:
+            # both pass streams must see the last optimizer step and the repacked weight images: pack once here, on the
+            # caller's stream, instead of inside the first forward pass (which the second stream would have to wait for)
+            net.prepack_weights()
+            pass_streams[1].wait_stream(torch.cuda.current_stream(device))
+        if hasattr(net, 'forward_one_stream'):
+            net.forward_one_stream = multi
+        for i, group in enumerate(groups):
+            run_group(group, pass_streams[i % 2] if multi else None)
         close_window_logs()
         epoch, _idx, _mb, end_of_epoch = window[-1]
         if end_of_epoch and is_snapshot_epoch(epoch) and parallel.rank() == 0:
@@ -341,6 +393,8 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         run_window(window)
 
     net.defer_wgrad_join = False  # joins
+    if hasattr(net, 'forward_one_stream'):
+        net.forward_one_stream = False
     net.compute_side_outputs = True
     time_enqueued = timeit.default_timer() - time_all_start  # how far ahead of the device the host loop ran
     if torch.cuda.is_available():
