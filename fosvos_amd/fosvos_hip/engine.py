@@ -299,6 +299,9 @@ def shared_stream(device_index: int, role: str) -> "torch.cuda.Stream":
         order = ("aux", "pass", "comm")  # creation order is part of the contract: the weight-gradient stream first
         for earlier in order[:order.index(role)] if role in order else ():
             shared_stream(device_index, earlier)
+        # lab switch FOSVOS_STREAM_SKIP_<ROLE>=k: k throw-away streams first (shifts the role onto another hardware queue)
+        skip = int(os.environ.get("FOSVOS_STREAM_SKIP_" + role.upper(), "0") or 0)
+        _SHARED_STREAMS[("skipped", role, device_index)] = [torch.cuda.Stream(device=device_index) for _ in range(skip)]
         st = _SHARED_STREAMS[key] = torch.cuda.Stream(device=device_index)
     return st
 
