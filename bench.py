@@ -282,7 +282,7 @@ def main():
     # the library's two auxiliary streams, created before anything else in this process creates streams (the process group,
     # RCCL): which hardware queue a stream gets depends on creation order, and two streams on one queue do not overlap
     from fosvos_hip import engine as _engine
-    _engine.shared_stream(dev_index, "pass")
+    _engine.shared_stream(dev_index, "comm")  # (creates all three, in order)
     distinct = 1
     if world > 1:
         dist.init_process_group(backend=backend)

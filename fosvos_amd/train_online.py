@@ -154,7 +154,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     if flat.flat.is_cuda:  # (both auxiliary streams exist from here on, in a fixed creation order: see engine.shared_stream)
         from fosvos_hip import engine as _engine0
         _engine0.shared_stream(flat.flat.device.index if flat.flat.device.index is not None else torch.cuda.current_device(),
-                               "pass")
+                               "comm")
     if (flat.flat.is_cuda and hasattr(net, 'join_gradients') and getattr(net, 'defer_wgrad_join', False)
             and os.environ.get('FOSVOS_PASS_STREAMS', '1') != '0'):
         from fosvos_hip import engine as _engine
