@@ -111,6 +111,8 @@ class FlatGrads:
         self._offsets = list(offs)
         for p, o in zip(self.params, offs):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
+        self._views = [p.grad for p in self.params]  # (identity of these objects = "nobody re-pointed a .grad since")
+        self.cache: dict = {}  # small per-loop constants of the training loops (device scalars, pinned staging), keyed by them
         # bucket b = one contiguous slice [lo, hi) of the flat buffer; without names: one bucket, everything.
         # Trainable tensors outside every bucket form trailing buckets of their own, except those under `frozen`:
         # the engine never produces a gradient for them (the reference keeps them at lr 0), their slice stays zero.
@@ -168,9 +170,22 @@ class FlatGrads:
     def still_attached(self, params: Sequence[torch.nn.Parameter]) -> bool:
         if len(params) != len(self.params) or any(a is not b for a, b in zip(params, self.params)):
             return False
+        if all(p.grad is v for p, v in zip(self.params, self._views)):  # the very view objects this buffer handed out
+            return True
         base, esz = self.flat.data_ptr(), self.flat.element_size()
         return all(p.grad is not None and p.grad.data_ptr() == base + o * esz and p.grad.numel() == p.numel()
                    for p, o in zip(self.params, self._offsets))
+
+    @classmethod
+    def attach_module(cls, net) -> "FlatGrads":
+        """`attach` for all parameters of `net`, named: the loops' entry.  With a buffer already attached the names are not
+        even listed (a training call of a few steps pays for every microsecond in front of its first kernel)."""
+        old = getattr(net, "_fosvos_flat_grads", None)
+        if old is not None and old.still_attached([p for p in net.parameters() if p.requires_grad]):
+            old.zero()
+            return old
+        named = list(net.named_parameters())
+        return cls.attach(net, [p for _, p in named], names=[n for n, _ in named])
 
     def zero(self, buckets: Optional[Sequence[int]] = None) -> None:
         """Zero the whole buffer, or only the slices of the given buckets."""

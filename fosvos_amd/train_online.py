@@ -127,8 +127,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     local_accum = parallel.split_accumulation(avg_grad_every_n, world)
     # gradients live in one flat fp32 buffer: the wgrad kernels accumulate straight into it, zeroing is one memset,
     # and under data parallelism it is the single all-reduce payload
-    named = list(net.named_parameters())
-    flat = parallel.FlatGrads.attach(net, [p for _, p in named], names=[n for n, _ in named])
+    flat = parallel.FlatGrads.attach_module(net)
     sync = parallel.GradSync(net, flat)
 
     # on the GPU the optimizer step is split by gradient bucket (see run_group); FOSVOS_SPLIT_STEP=0 = one step
@@ -166,9 +165,14 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     counter_gradient = 0
     log_every = max(n_epochs // 20, 1)  # the reference divides by n_epochs // 20, which is 0 below 20 epochs
     device = next(net.parameters()).device
-    inv_avg = torch.ones((), device=device) / avg_grad_every_n
     max_group = _max_group()
-    inv_avg_k = torch.full((max_group,), 1.0 / avg_grad_every_n, device=device)  # backward seed of a batched pass
+    consts = flat.cache.get(('online', avg_grad_every_n, max_group, str(device)))
+    if consts is None:  # (constants of the loop, kept with the gradient buffer: a short call should not re-create them)
+        consts = flat.cache[('online', avg_grad_every_n, max_group, str(device))] = {
+            'inv_avg': torch.ones((), device=device) / avg_grad_every_n,
+            'inv_avg_k': torch.full((max_group,), 1.0 / avg_grad_every_n, device=device),  # backward seed of a batched pass
+            'ring': torch.empty((64, max_group), dtype=torch.float32).pin_memory() if device.type == 'cuda' else None}
+    inv_avg, inv_avg_k = consts['inv_avg'], consts['inv_avg_k']
 
     # The reference reads loss.item() every iteration and the running loss at 20 logging points per run (device->host
     # syncs that drain the launch queue).  Here every pass sends its per-frame losses to pinned memory with ONE asynchronous
@@ -177,7 +181,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     pending_logs = []   # per window: ([(epoch, minibatch index, host tensor, position)] in iteration order, event, ring slots)
     ring, ring_free = None, []
     if device.type == 'cuda':
-        ring = torch.empty((64, max_group), dtype=torch.float32).pin_memory()
+        ring = consts['ring']  # (every slot is free again: the previous call ended with a device sync)
         ring_free = list(range(ring.shape[0]))
     running_host = [0.0]
 
