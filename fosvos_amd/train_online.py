@@ -150,16 +150,14 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     # run beside the backward pass of the previous one (their weight-gradient kernels share one stream and stay in order, so
     # the accumulation into the gradients does too).  FOSVOS_PASS_STREAMS=0: one stream.
     pass_streams = None
-    if flat.flat.is_cuda:  # (both auxiliary streams exist from here on, in a fixed creation order: see engine.shared_stream)
-        from fosvos_hip import engine as _engine0
-        _engine0.shared_stream(flat.flat.device.index if flat.flat.device.index is not None else torch.cuda.current_device(),
-                               "comm")
-    if (flat.flat.is_cuda and hasattr(net, 'join_gradients') and getattr(net, 'defer_wgrad_join', False)
-            and os.environ.get('FOSVOS_PASS_STREAMS', '1') != '0'):
+    if flat.flat.is_cuda:
         from fosvos_hip import engine as _engine
-        _dev = flat.flat.device
-        pass_streams = [None, _engine.shared_stream(_dev.index if _dev.index is not None else torch.cuda.current_device(),
-                                                    "pass")]  # None = the caller's stream
+        dev_index = flat.flat.device.index if flat.flat.device.index is not None else torch.cuda.current_device()
+        # the library's auxiliary streams exist from here on, in their fixed creation order (engine.shared_stream)
+        _engine.shared_stream(dev_index, "comm")
+        if (hasattr(net, 'join_gradients') and getattr(net, 'defer_wgrad_join', False)
+                and os.environ.get('FOSVOS_PASS_STREAMS', '1') != '0'):
+            pass_streams = [None, _engine.shared_stream(dev_index, "pass")]  # None = the caller's stream
     n_samples = len(dataloader)
     loss_tr = []
     counter_gradient = 0
