@@ -313,7 +313,9 @@ class ArenaPool:
         self._free: Dict[Tuple[int, int, int, int], List[torch.Tensor]] = {}
         self._aux: Dict[int, "torch.cuda.Stream"] = {}
         self._ctx: Dict[int, "Context"] = {}  # the model's execution context per device (events of its two-stream passes)
-        self._pending: List[Tuple[int, int, int, torch.Tensor]] = []  # arenas still read by deferred wgrad kernels
+        # arenas (and the frames of their passes: conv1_1's weight gradient reads the frame itself) that deferred
+        # weight-gradient kernels on the auxiliary stream may still read
+        self._pending: List[Tuple[int, int, int, torch.Tensor, Optional[torch.Tensor]]] = []
 
     def aux_stream(self, device_index: int) -> int:
         """Handle of the auxiliary HIP stream the backward pass issues its weight-gradient kernels on
@@ -340,14 +342,14 @@ class ArenaPool:
         nbytes = lib().fosvos_vgg_arena_bytes(n, h, w)
         return torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
 
-    def hold(self, n: int, h: int, w: int, arena: torch.Tensor) -> None:
-        self._pending.append((n, h, w, arena))
+    def hold(self, n: int, h: int, w: int, arena: torch.Tensor, frame: Optional[torch.Tensor] = None) -> None:
+        self._pending.append((n, h, w, arena, frame))
 
     def join(self) -> None:
         """Make the current stream wait for every deferred weight-gradient kernel, then recycle their arenas."""
         for idx, st in self._aux.items():
             torch.cuda.current_stream(idx).wait_stream(st)
-        for n, h, w, arena in self._pending:
+        for n, h, w, arena, _frame in self._pending:
             self.give(n, h, w, arena)
         self._pending.clear()
 
@@ -506,7 +508,7 @@ def native_backward(P, packs, saved, d_outs, inplace: bool, defer_join: bool = F
                 grads[f"score_dsn.{i}.weight"], grads[f"score_dsn.{i}.bias"] = gw.clone(), gb.clone()
     del hold, keep_alive
     if g.defer_join:
-        packs.arenas.hold(N, H, W, arena)
+        packs.arenas.hold(N, H, W, arena, x)
     else:
         packs.arenas.give(N, H, W, arena)
     return grads

@@ -176,7 +176,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     # syncs that drain the launch queue).  Here every pass sends its per-frame losses to pinned memory with ONE asynchronous
     # copy and the host does the bookkeeping (running sum, logging points) once the copy has landed: no device-side
     # accumulator kernels, no sync.  `loss_tr` fills in iteration order, a few passes behind the device.
-    pending_logs = []   # per window: ([(epoch, minibatch index, host tensor, position)] in iteration order, event, ring slots)
+    pending_logs = []   # per window: ([(epoch, minibatch index, host tensor, position)] in iteration order, events, ring slots)
     ring, ring_free = None, []
     if device.type == 'cuda':
         ring = consts['ring']  # (every slot is free again: the previous call ended with a device sync)
@@ -186,9 +186,12 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     def flush_logs(block: bool) -> None:
         while pending_logs:
             items, landed, slots = pending_logs[0]
+            # every pass's copy has its own event: the passes of a window alternate between two streams, so the last
+            # event alone says nothing about the copies queued on the other stream
             if block:
-                landed.synchronize()
-            elif not landed.query():
+                for ev in landed:
+                    ev.synchronize()
+            elif not all(ev.query() for ev in landed):
                 break
             pending_logs.pop(0)
             for ep, mb, host_vals, i in items:  # iteration order of the reference's loop, whatever order the passes ran in
@@ -224,13 +227,13 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
 
     def close_window_logs() -> None:
         """The passes of a window ran bucket by bucket; the bookkeeping (running loss, logging points) follows the
-        reference's iteration order: one pending entry per window, sorted, waiting on the window's last copy."""
+        reference's iteration order: one pending entry per window, sorted, waiting on the copies of ALL its passes."""
         if not window_logs:
             return
         items = sorted(((ep, mb, host_vals, i) for frames, host_vals, _, _ in window_logs
                         for i, (ep, mb) in enumerate(frames)), key=lambda t: (t[0], t[1]))
         slots = [slot for _, _, _, slot in window_logs if slot is not None]
-        pending_logs.append((items, window_logs[-1][2], slots))
+        pending_logs.append((items, [landed for _, _, landed, _ in window_logs], slots))
         window_logs.clear()
         flush_logs(False)
 
@@ -241,6 +244,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         return (epoch % snapshot_every_n) == snapshot_every_n - 1
 
     side_stream_used = [False]  # a pass of the current cycle ran on pass_streams[1]: the optimizer step waits for it
+    last_pass_on_side = [False]  # ... and it was the most recent pass
 
     def run_group(group, stream=None) -> None:
         """One forward / loss / backward pass over the micro-batches of `group` (iterations of the reference's loop with
@@ -251,6 +255,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         split-K, fewer launch gaps) and one set of weight-gradient partial slabs per group instead of per frame."""
         nonlocal counter_gradient, n_iters
         k = len(group)
+        last_pass_on_side[0] = stream is not None
         if stream is not None:
             side_stream_used[0] = True
             with torch.cuda.stream(stream):
@@ -305,8 +310,12 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
 
     def wait_side_stream() -> None:
         """The caller's stream waits for the passes of this cycle that ran on the second pass stream.  (The EARLY part of a
-        split optimizer step does not need this: the weight-gradient kernels of all passes share one stream, so the bucket
-        events of the cycle's last pass also say that every earlier pass is done with the stages they cover.)"""
+        split optimizer step does not need this for the EARLIER passes: the weight-gradient kernels of all passes share one
+        stream, in order, and a pass's last weight-gradient kernels wait for the end of its data-gradient chain, so the
+        bucket events of the cycle's last pass also say that every earlier pass has left the stages they cover.  The closing
+        pass's OWN data-gradient chain is not covered by its bucket events - a stage's event is recorded behind the weight
+        gradient of the stage's first conv, which is issued in front of that conv's data gradient - so the closing pass runs
+        on the caller's stream, where the step queues behind it; see run_window and close_cycle_if_due.)"""
         if side_stream_used[0]:
             torch.cuda.current_stream(device).wait_stream(pass_streams[1])
             side_stream_used[0] = False
@@ -323,6 +332,10 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
                 # Data parallel: "final" means all-reduced - the early buckets' collectives were begun while the backward pass
                 # was still running, and each is waited for on its own.
                 net.publish_grad_buckets = False
+                if last_pass_on_side[0]:
+                    # (run_window schedules a window's last pass on the caller's stream, so this is a guard: the early step
+                    # rewrites and repacks weights the closing pass's data-gradient chain on the other stream still reads)
+                    wait_side_stream()
                 for b in early_buckets:
                     if world > 1:
                         sync.wait_bucket(b)
@@ -369,7 +382,13 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         if hasattr(net, 'forward_one_stream'):
             net.forward_one_stream = multi
         for i, group in enumerate(groups):
-            run_group(group, pass_streams[i % 2] if multi else None)
+            # the window's LAST pass (the one that may close the cycle) always runs on the caller's stream: the split
+            # optimizer step is queued there, behind that pass's data-gradient chain
+            run_group(group, pass_streams[(len(groups) - 1 - i) % 2] if multi else None)
+        if multi:
+            # the window's minibatches were allocated on the caller's stream and read on the other one: before they are
+            # released (window = [] below; a window can end without a cycle close) the caller's stream waits for it
+            wait_side_stream()
         close_window_logs()
         epoch, _idx, _mb, end_of_epoch = window[-1]
         if end_of_epoch and is_snapshot_epoch(epoch) and parallel.rank() == 0:

@@ -86,9 +86,10 @@ def full_or_dense(store, prefix, name, d):
         store[f"{prefix}_dense_{name}_s"] = smp.astype(np.float32)
 
 
-def trajectory_fixture(OSVOS_VGG, RL, RNP, O):
-    TRAJ = O.TRAJ
-    sd0, frames, (xh, gh) = O.trajectory_inputs()
+def trajectory_fixture(OSVOS_VGG, RL, RNP, O, TRAJ=None, compact=False):
+    """compact (the 480x854 fixture): logit maps as fp16 + their fp32 absolute maximum, full deltas as fp32."""
+    TRAJ = O.TRAJ if TRAJ is None else TRAJ
+    sd0, frames, (xh, gh) = O.trajectory_inputs(TRAJ)
     net = OSVOS_VGG(pretrained=0)
     net.load_state_dict(sd0)
     cls = RNP.VGGOnlineProvider
@@ -115,16 +116,22 @@ def trajectory_fixture(OSVOS_VGG, RL, RNP, O):
         seen = net.forward(frames[0][0])[-1]
     out = {k: np.float64(v) if isinstance(v, float) else np.int64(v) for k, v in TRAJ.items()}
     out["loss"] = np.array(trace, dtype=np.float64)
-    out["heldout_logits_start"] = start[0, 0].numpy().copy()
-    out["heldout_logits"] = held[0, 0].numpy().copy()
+    if compact:
+        out["heldout_logits_f16"] = held[0, 0].numpy().astype(np.float16)
+        out["heldout_logits_absmax"] = np.float32(held.abs().max().item())
+        out["heldout_start_mask_bits"] = np.packbits((start[0, 0] >= 0).numpy())
+        out["train_mask_bits"] = np.packbits((seen[0, 0] >= 0).numpy())
+    else:
+        out["heldout_logits_start"] = start[0, 0].numpy().copy()
+        out["heldout_logits"] = held[0, 0].numpy().copy()
+        out["train_logits"] = seen[0, 0].numpy().copy()
     out["heldout_mask_bits"] = np.packbits((held[0, 0] >= 0).numpy())
     out["heldout_gt_bits"] = np.packbits((gh[0, 0] > 0.5).numpy())
-    out["train_logits"] = seen[0, 0].numpy().copy()
     full, digested = [], []
     for name, p in net.named_parameters():
         d = p.detach().double() - sd0[name].double()
         if d.numel() <= 65536:
-            out[f"delta_{name}"] = d.numpy().astype(np.float64)
+            out[f"delta_{name}"] = d.numpy().astype(np.float32 if compact else np.float64)
             full.append(name)
         else:
             m, idx, smp = digest(d, n_samples=4096)
@@ -139,7 +146,8 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
     ap.add_argument("--skip-e2e", action="store_true")
-    ap.add_argument("--only", default=None, help="write only this fixture (kat, stacks, net, loops, e2e, trajectory)")
+    ap.add_argument("--only", default=None,
+                    help="write only this fixture (kat, stacks, net, loops, e2e, trajectory, bwd_full, trajectory_full)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     logging.disable(logging.CRITICAL)
@@ -381,6 +389,40 @@ def main() -> None:
     if args.only in (None, "trajectory"):
         traj = trajectory_fixture(OSVOS_VGG, RL, RNP, O)
         np.savez_compressed(os.path.join(args.out, "trajectory.npz"), **traj)
+    # ------------------------------------------------------------------ 7. backward pass at the BASELINE frame size
+    # ONE reference forward + class-balanced loss + backward of the online objective (src/train_online.py:79-93,
+    # src/networks/osvos_vgg.py:61-83) on the 1x3x480x854 frame of section 5, same net: every gradient - tensors of at
+    # most 64 k elements whole, the larger ones as 4096 strided samples - plus float64 moments (sum, sum |g|, sum g^2) of
+    # ALL elements of every tensor.
+    if not args.skip_e2e and args.only in (None, "bwd_full"):
+        net, _ = ref_net(9)
+        x, gt = O.synthetic_frame(1, 480, 854, seed=1234)
+        outs = net.forward(x)
+        loss = RL.class_balanced_cross_entropy_loss(outs[-1], gt, size_average=False)
+        net.zero_grad()
+        loss.backward()
+        bwd = {"seed": np.int64(9), "frame_seed": np.int64(1234), "loss_fused_sum": np.float64(loss.item())}
+        full, dense, nograd = [], [], []
+        for name, p in net.named_parameters():
+            if p.grad is None:
+                nograd.append(name)
+                continue
+            m, idx, smp = digest(p.grad, n_samples=4096)
+            bwd[f"g_{name}_m"] = m
+            if p.grad.numel() <= 65536:
+                bwd[f"g_{name}"] = p.grad.numpy().copy()
+                full.append(name)
+            else:
+                bwd[f"g_{name}_i"], bwd[f"g_{name}_s"] = idx, smp
+                dense.append(name)
+        bwd["full_tensors"], bwd["dense_tensors"], bwd["nograd"] = np.array(full), np.array(dense), np.array(nograd)
+        np.savez_compressed(os.path.join(args.out, "bwd_480x854.npz"), **bwd)
+    # ------------------------------------------------------------------ 8. fine-tune TRAJECTORY at the BASELINE frame size
+    # Section 6's schedule on 1x3x480x854 frames (O.TRAJ_FULL: 30 iterations, step every 5, then the held-out frame): the
+    # size north_star's "mask IoU within 1e-3 of the reference" is quoted on.  A few minutes of reference CPU time.
+    if not args.skip_e2e and args.only in (None, "trajectory_full"):
+        traj = trajectory_fixture(OSVOS_VGG, RL, RNP, O, O.TRAJ_FULL, compact=True)
+        np.savez_compressed(os.path.join(args.out, "trajectory_480x854.npz"), **traj)
     print("golden fixtures written to", args.out)
 
 

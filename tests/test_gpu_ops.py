@@ -423,6 +423,63 @@ def test_conv3x3_wgrad_five_frames(ops):
     assert torch.equal(dw2, dw) and torch.equal(db2, db)
 
 
+def _wgrad_ref(x, dy, co, ci):
+    """torch fp32 on the CPU, image by image, the images' gradients added in float64 (so that the reference's own fp32
+    accumulation over 2 M pixels is not what the comparison measures)."""
+    dw = torch.zeros(co, ci, 3, 3, dtype=torch.float64)
+    db = torch.zeros(co, dtype=torch.float64)
+    for i in range(x.shape[0]):
+        wt = torch.zeros(co, ci, 3, 3, requires_grad=True)
+        b = torch.zeros(co, requires_grad=True)
+        F.conv2d(x[i:i + 1], wt, b, padding=1).backward(dy[i:i + 1])
+        dw += wt.grad.double()
+        db += b.grad.double()
+    return dw, db
+
+
+# The weight-gradient kernels ON THE SHAPES OF THE 480x854 STEP (five frames per launch): the backbone form on conv1_2's map
+# (2 M pixels over 192 pixel splits, multi-image tiles, the largest launch of the step), the side_prep form (16 outputs in a
+# 32-wide gradient image) on the largest and the smallest side map, conv1_1's 27-column form.  Each against torch fp32 on
+# the same bf16 operands; fixed-order reductions, so a second launch is bit-identical.
+@pytest.mark.parametrize("n,h,w,ci,co", [(5, 480, 854, 64, 64), (5, 240, 427, 128, 16), (5, 30, 54, 512, 16)])
+def test_conv3x3_wgrad_step_shapes(ops, n, h, w, ci, co):
+    x = bf(gen(n, ci, h, w, seed=140))
+    dy = bf(gen(n, co, h, w, seed=141))
+    dw_ref, db_ref = _wgrad_ref(x, dy, co, ci)
+    cy = (co + 31) // 32 * 32
+    dy_dev = torch.zeros(n, h, w, cy, dtype=torch.bfloat16, device=DEV)
+    dy_dev[..., :co] = to_nhwc_bf16(dy)
+    xd = to_nhwc_bf16(x)
+    del x, dy
+    dw, db = ops.conv3x3_wgrad(xd, dy_dev, ci, co)
+    assert dw.shape == (co, ci, 3, 3)
+    e_w, e_b = rel_err(dw.cpu().double(), dw_ref), rel_err(db.cpu().double(), db_ref)
+    print(f"[wgrad {n}x{h}x{w} {ci}->{co}] rel-to-max err dw {e_w:.2e} db {e_b:.2e}")
+    assert e_w < 5e-5 and e_b < 5e-5
+    dw2, db2 = ops.conv3x3_wgrad(xd, dy_dev, ci, co)
+    assert torch.equal(dw2, dw) and torch.equal(db2, db)
+    # accumulate mode on top of existing gradients (what the training loops run)
+    dw3, db3 = ops.conv3x3_wgrad(xd, dy_dev, ci, co, dw=dw.clone(), db=db.clone(), accumulate=True)
+    assert torch.equal(dw3, 2 * dw) and torch.equal(db3, 2 * db)
+
+
+def test_conv_first_wgrad_step_shape(ops):
+    """conv1_1's weight gradient at five 480x854 frames (the frame rounded to bf16 inside the kernel, like every other
+    weight gradient reads bf16 activations; fp32 accumulate)."""
+    n, h, w = 5, 480, 854
+    x = gen(n, 3, h, w, seed=142, scale=60.0)
+    dy = bf(gen(n, 64, h, w, seed=143))
+    dw_ref, db_ref = _wgrad_ref(bf(x), dy, 64, 3)
+    dyd = to_nhwc_bf16(dy)
+    del dy
+    dw, db = ops.conv3x3_first_wgrad(x.to(DEV), dyd)
+    e_w, e_b = rel_err(dw.cpu().double(), dw_ref), rel_err(db.cpu().double(), db_ref)
+    print(f"[first wgrad {n}x{h}x{w}] rel-to-max err dw {e_w:.2e} db {e_b:.2e}")
+    assert e_w < 5e-5 and e_b < 5e-5
+    dw2, db2 = ops.conv3x3_first_wgrad(x.to(DEV), dyd)
+    assert torch.equal(dw2, dw) and torch.equal(db2, db)
+
+
 # ------------------------------------------------------------------------------------------ pool
 @pytest.mark.parametrize("n,h,w,c", [(1, 48, 86, 64), (2, 61, 107, 64), (1, 1, 1, 64), (1, 2, 3, 128), (1, 7, 1, 64)])
 def test_maxpool(ops, n, h, w, c):
