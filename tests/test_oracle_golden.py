@@ -266,6 +266,60 @@ def test_e2e_frame(golden):
         check_digest(outs[i], k[f"side{i}_m"], k[f"side{i}_i"], k[f"side{i}_s"], rtol=1e-4)
 
 
+def test_backward_480x854(golden):
+    """The oracle's backward pass at the BASELINE frame size against the reference's (oracle/make_golden.py section 7): the
+    fused loss and every gradient - small tensors element by element, the larger ones on their 4096 strided samples and
+    float64 moments."""
+    k = golden("bwd_480x854.npz")
+    sd = O.make_state_dict(int(k["seed"]))
+    x, gt = O.synthetic_frame(1, 480, 854, seed=int(k["frame_seed"]))
+    params = O.leaf_params(sd)
+    loss = O.cbce_loss(O.forward(params, x)[-1], gt, size_average=False)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(k["loss_fused_sum"]), rtol=1e-5)
+    for nm in k["nograd"]:
+        assert params[str(nm)].grad is None, nm
+    for nm in list(k["full_tensors"]) + list(k["dense_tensors"]):
+        nm = str(nm)
+        g = params[nm].grad.double().reshape(-1)
+        if f"g_{nm}" in k.files:
+            ref = torch.from_numpy(k[f"g_{nm}"]).double().reshape(-1)
+            got = g
+        else:
+            ref = torch.from_numpy(k[f"g_{nm}_s"]).double()
+            got = g[torch.from_numpy(k[f"g_{nm}_i"])]
+        # two statements of one fp32 graph over 410 k pixels (nn modules vs functional calls, threaded reductions)
+        assert float((got - ref).norm()) <= 2e-3 * float(ref.norm()) + 1e-30, nm
+        m = k[f"g_{nm}_m"]
+        np.testing.assert_allclose(float(g.abs().sum()), m[1], rtol=2e-3)
+        np.testing.assert_allclose(float((g * g).sum()), m[2], rtol=4e-3)
+
+
+def test_finetune_trajectory_480x854_first_cycle(golden):
+    """The 480x854 fine-tune fixture (oracle/make_golden.py section 8; 30 reference iterations): the oracle follows its first
+    accumulation cycle, optimizer step and the next iteration (6 forward / backward passes: about a minute of CPU time;
+    the GPU test runs the whole schedule), and the fixture is self-consistent (schedule constants, mask bits = sign of the
+    stored logits outside fp16 resolution, the run trains)."""
+    k = golden("trajectory_480x854.npz")
+    for key, val in O.TRAJ_FULL.items():
+        assert float(k[key]) == float(val), key
+    assert len(k["loss"]) == O.TRAJ_FULL["iters"] and k["loss"][-1] < 0.15 * k["loss"][0]
+    sd, frames, (xh, gh) = O.trajectory_inputs(O.TRAJ_FULL)
+    losses, _ = O.online_loop(sd, [f[0] for f in frames], [f[1] for f in frames], O.TRAJ_FULL["avg"] + 1,
+                              O.TRAJ_FULL["avg"], lr=O.TRAJ_FULL["lr"])
+    np.testing.assert_allclose(losses, k["loss"][:len(losses)], rtol=1e-3)
+    ref = torch.from_numpy(k["heldout_logits_f16"].astype(np.float32))
+    n = ref.numel()
+    ref_mask = torch.from_numpy(np.unpackbits(k["heldout_mask_bits"])[:n].reshape(ref.shape)).bool()
+    sure = ref.abs() > 2e-3 * float(k["heldout_logits_absmax"])
+    assert torch.equal((ref >= 0)[sure], ref_mask[sure])
+    gt_mask = torch.from_numpy(np.unpackbits(k["heldout_gt_bits"])[:n].reshape(ref.shape)).bool()
+    assert torch.equal(gt_mask, gh[0, 0] > 0.5)
+    start_mask = torch.from_numpy(np.unpackbits(k["heldout_start_mask_bits"])[:n].reshape(ref.shape)).bool()
+    assert O.mask_iou(start_mask, gt_mask) < 0.05 < 0.9 < O.mask_iou(ref_mask, gt_mask)  # the mask moved onto the object
+    assert len(k["full_tensors"]) + len(k["digest_tensors"]) == 52
+
+
 def test_bf16_emulation_mode_is_close_to_fp32():
     """The bf16-emulating oracle mode (used to separate precision scheme from kernel correctness in the GPU
     tests) is the same graph plus rounding: its logits stay within 2 % of the fp32 logit range."""
