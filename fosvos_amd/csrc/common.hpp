@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/fosvos_hip.h"
@@ -118,6 +119,25 @@ inline int ctx_check(const fosvos_ctx *ctx, const char *who) {
     FOSVOS_REQUIRE(ctx->magic == kFosvosCtxMagic, FOSVOS_E_ARG, "%s: not a live fosvos_ctx", who);
     return FOSVOS_OK;
 }
+
+// Lab switches: FOSVOS_* environment variables steer A/B experiments in LAB builds only (make LAB=1 -> -DFOSVOS_LAB_BUILD).
+// The shipped library reads no environment: every site below sees "unset" and takes its measured default, so the C ABI has
+// no hidden inputs (no global mutable state).
+#ifdef FOSVOS_LAB_BUILD
+inline const char *lab_env(const char *name) { return getenv(name); }
+#else
+inline const char *lab_env(const char *) { return nullptr; }
+#endif
+inline int lab_env_int(const char *name, int dflt) {
+    const char *e = lab_env(name);
+    return e ? atoi(e) : dflt;
+}
+
+// Persistent eight-wave forward conv (conv_pp.hip): which launches take it, and the launch itself.
+bool conv_pp_applicable(int N, int H, int W, int in_ch, int out_ch);
+int conv_pp_workgroups();
+int conv_pp_forward(const uint16_t *x, const uint16_t *w_packed, const float *bias, uint16_t *y, uint16_t *y_pool, int N,
+                    int H, int W, int Cin_pad, int Cout, int Co_pad, bool relu, hipStream_t st);
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int roundup(int a, int b) { return (a + b - 1) / b * b; }

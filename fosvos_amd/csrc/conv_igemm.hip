@@ -637,13 +637,13 @@ ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
         // stream, which fills the second slot of each CU); below that the 128-pixel tile, 3 per CU
         // ... unless the 128-pixel tiles still fit in ONE round (3 per CU = 768): five frames of the 30x54x512 layers are 320
         // big workgroups (62 % of the 512 slots, 16 chunks each) or 640 small ones: 53 against 60 us per launch alone
-        static const bool one_round = !(getenv("FOSVOS_MID_ONE_ROUND") && atoi(getenv("FOSVOS_MID_ONE_ROUND")) == 0);
+        static const bool one_round = lab_env_int("FOSVOS_MID_ONE_ROUND", 1) != 0;
         const bool mid_fits_a_round = one_round && blocks(8, 16, 64) <= 768 && blocks(8, 32, 64) < kMinBlocks * 3 / 4;
         if (blocks(8, 32, 64) >= kMinBlocks / 2 && !mid_fits_a_round) {
             // ... as 8 x 32 or as 16 x 16 pixels, whichever overhangs the map less (a tile computes all of its 256 pixels:
             // 60 x 107 is 64 x 128 = 8192 pixels of work in 8 x 32 tiles, 64 x 112 = 7168 in 16 x 16 ones)
             const int64_t area_wide = cdiv(H, 8) * 8 * cdiv(W, 32) * 32, area_sq = cdiv(H, 16) * 16 * cdiv(W, 16) * 16;
-            static const bool allow_sq = !(getenv("FOSVOS_NO_SQUARE_TILE") && atoi(getenv("FOSVOS_NO_SQUARE_TILE")));
+            static const bool allow_sq = lab_env_int("FOSVOS_NO_SQUARE_TILE", 0) == 0;
             if (allow_sq && area_sq < area_wide) { p.tile = kSquare; nb = blocks(16, 16, 64); }
             else { p.tile = kBig; nb = blocks(8, 32, 64); }
         } else { p.tile = kMid; nb = blocks(8, 16, 64); }
@@ -656,7 +656,7 @@ ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
     }
     if (out_ch % 64 == 0) {
         // lab switch: 0 = 8x32, 1 = 8x16, 2 = 4x16 pixel tiles of 64 channels; 5 = 8x32 pixels x 32 channels
-        static const char *force = getenv("FOSVOS_FORCE_TILE");
+        static const char *force = lab_env("FOSVOS_FORCE_TILE");
         if (force && ((atoi(force) >= 0 && atoi(force) <= 2) || atoi(force) == (int)kHalf)) {
             p.tile = (TileId)atoi(force);
             nb = p.tile == kBig ? blocks(8, 32, 64) : p.tile == kMid ? blocks(8, 16, 64)
@@ -671,7 +671,7 @@ ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
         if (ks > 16) ks = 16;
     }
 #ifdef FOSVOS_STAMP
-    if (const char *e = getenv("FOSVOS_FORCE_KS")) ks = atoi(e);
+    if (const char *e = lab_env("FOSVOS_FORCE_KS")) ks = atoi(e);
 #endif
     p.chunks_per_split = (int)cdiv(n_chunks, ks);
     p.k_splits = (int)cdiv(n_chunks, p.chunks_per_split);
@@ -708,7 +708,7 @@ int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st, int in_ch) 
         prof_begin(name, st, 2.0 * a.N * a.H * a.W * 9.0 * in_ch * a.Cout);
     }
     {
-        static const int swz_env = getenv("FOSVOS_IGEMM_SWIZZLE") ? atoi(getenv("FOSVOS_IGEMM_SWIZZLE")) : -1;  // lab switch
+        static const int swz_env = lab_env_int("FOSVOS_IGEMM_SWIZZLE", -1);  // lab switch
         const int n_cb = a.Cout / T::BN;
         // Measured at five 480x854 frames per launch, every layer alone: mode 1 -2.6 % forward / -1.6 % data gradient over the
         // plain mapping (conv3 -3..-4.5 %, conv2_1 forward -6 %), also for the 512-channel layers whose 4.7 MB of weights do
@@ -776,6 +776,15 @@ int dispatch(ConvArgs a, int in_ch, void *workspace, size_t workspace_bytes, hip
     return fail(FOSVOS_E_ARG, "conv3x3: bad plan");
 }
 
+// Forward launches with bf16 output and no addend take the persistent eight-wave kernel (conv_pp.hip) where its tiles fill
+// the chip.  Lab builds: FOSVOS_PP=0 never, 1 whenever the shape fits.
+bool forward_takes_pp(int N, int H, int W, int in_ch, int out_ch, unsigned flags) {
+    if (flags & ~FOSVOS_CONV_RELU) return false;
+    static const int mode = lab_env_int("FOSVOS_PP", -1);
+    if (mode == 0) return false;
+    return conv_pp_applicable(N, H, W, roundup(in_ch, 32), out_ch);
+}
+
 int check_common(const void *x, const void *w, const void *y, int N, int H, int W, int in_ch, int out_ch,
                  const char *who) {
     FOSVOS_REQUIRE(x && w && y, FOSVOS_E_ARG, "%s: null pointer", who);
@@ -813,6 +822,19 @@ extern "C" int fosvos_conv3x3_plan(int N, int H, int W, int in_ch, int out_ch, f
     out->tile_h = th; out->tile_w = tw; out->tile_co = bn;
     out->k_splits = p.k_splits;
     out->workgroups = (int)(cdiv(W, tw) * cdiv(H, th) * N * (out_ch / bn));
+    out->persistent = 0;
+    return FOSVOS_OK;
+}
+
+extern "C" int fosvos_conv3x3_fwd_plan(int N, int H, int W, int in_ch, int out_ch, unsigned flags,
+                                       fosvos_conv3x3_plan_info *out) {
+    if (int rc = fosvos_conv3x3_plan(N, H, W, in_ch, out_ch, out)) return rc;
+    if (out_ch % 64 == 0 && forward_takes_pp(N, H, W, in_ch, out_ch, flags)) {
+        out->tile_h = 8; out->tile_w = 32; out->tile_co = 64;
+        out->k_splits = 1;
+        out->workgroups = conv_pp_workgroups();
+        out->persistent = 1;
+    }
     return FOSVOS_OK;
 }
 
@@ -822,6 +844,9 @@ extern "C" int fosvos_conv3x3_fwd(const uint16_t *x, const uint16_t *w_packed, c
     if (int rc = check_common(x, w_packed, y, N, H, W, Ci, Co, "conv3x3_fwd")) return rc;
     FOSVOS_REQUIRE((flags & ~(FOSVOS_CONV_RELU | FOSVOS_CONV_OUT_F32)) == 0, FOSVOS_E_ARG, "conv3x3_fwd: unknown flags 0x%x", flags);
     FOSVOS_ENTER(device);
+    if (Co % 64 == 0 && forward_takes_pp(N, H, W, Ci, Co, flags))
+        return conv_pp_forward(x, w_packed, bias, (uint16_t *)y, nullptr, N, H, W, roundup(Ci, 32), Co, roundup(Co, 16),
+                               (flags & FOSVOS_CONV_RELU) != 0, (hipStream_t)stream);
     ConvArgs a{};
     a.x = x; a.w = w_packed; a.bias = bias; a.relu_src = nullptr; a.addend = nullptr; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Cin = roundup(Ci, 32); a.Cout = Co; a.Co_pad = roundup(Co, 16); a.flags = flags;
@@ -868,6 +893,11 @@ extern "C" int fosvos_conv3x3_fwd_pool(const uint16_t *x, const uint16_t *w_pack
     FOSVOS_REQUIRE(y_pool, FOSVOS_E_ARG, "conv3x3_fwd_pool: null pooled output");
     FOSVOS_REQUIRE((flags & ~FOSVOS_CONV_RELU) == 0, FOSVOS_E_ARG, "conv3x3_fwd_pool: unknown flags 0x%x", flags);
     FOSVOS_REQUIRE(Co % 64 == 0, FOSVOS_E_SHAPE, "conv3x3_fwd_pool: Co=%d must be a multiple of 64", Co);
+    if ((flags & FOSVOS_CONV_RELU) && forward_takes_pp(N, H, W, Ci, Co, flags)) {  // (the fused pool takes post-ReLU values)
+        FOSVOS_ENTER(device);
+        return conv_pp_forward(x, w_packed, bias, y, y_pool, N, H, W, roundup(Ci, 32), Co, roundup(Co, 16), true,
+                               (hipStream_t)stream);
+    }
     if (make_plan(N, H, W, Ci, Co).k_splits > 1) {  // small maps (split-K): the epilogue kernel has no tile to pool
         if (int rc = fosvos_conv3x3_fwd(x, w_packed, bias, y, N, H, W, Ci, Co, flags, workspace, workspace_bytes, device, stream))
             return rc;

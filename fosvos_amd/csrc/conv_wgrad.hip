@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradReduceTable t) 
 
 int target_blocks() {  // FOSVOS_WGRAD_BLOCKS: lab switch, read once
     static const int v = [] {
-        const char *e = getenv("FOSVOS_WGRAD_BLOCKS");
+        const char *e = lab_env("FOSVOS_WGRAD_BLOCKS");
         const int n = e ? atoi(e) : 0;
         // The weight-gradient kernels run BESIDE the data-gradient chain (vgg_net.hip), and a CU that hosts one of these
         // workgroups has room for one igemm workgroup instead of two; slab bytes grow with the workgroup count.  Measured on
@@ -579,12 +579,12 @@ int fosvos::wgrad_impl(const uint16_t *x, const uint16_t *dy, float *dw, float *
     a.S = p.S; a.n_ci = Ci / 64; a.n_co = p.side ? 1 : p.Cor / 64;
     {
 #ifdef FOSVOS_LAB_BUILD  // timing experiments only (never in the shipped library: the switch drops the slab stores)
-        static const int lab = getenv("FOSVOS_WGRAD_LAB") ? atoi(getenv("FOSVOS_WGRAD_LAB")) : 0;
+        static const int lab = lab_env_int("FOSVOS_WGRAD_LAB", 0);
         a.lab = lab;
 #else
         a.lab = 0;
 #endif
-        const char *e = getenv("FOSVOS_WGRAD_XCD");  // lab switch (read per call: one process can A/B): 0 = plain workgroup order
+        const char *e = lab_env("FOSVOS_WGRAD_XCD");  // lab switch (read per call: one process can A/B): 0 = plain workgroup order
         a.xcd_order = !(e && atoi(e) == 0);
     }
     static bool once[64][2];  // per device: opt in to the dynamic LDS size

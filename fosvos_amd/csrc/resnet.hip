@@ -713,12 +713,12 @@ ConvLaunch plan_conv2d(int64_t npix, int Cop, int cic) {
         if (cdiv(npix, 64) * nb >= 2048) break;
     }
 #ifdef FOSVOS_CONV2D_LAB
-    if (const char *e = getenv("FOSVOS_COB")) pick = atoi(e);
+    if (const char *e = lab_env("FOSVOS_COB")) pick = atoi(e);
 #endif
     const int nb = (Cop + pick - 1) / pick;
     const int64_t waves = cdiv(npix, 64) * nb;
 #ifdef FOSVOS_CONV2D_LAB
-    if (const char *e = getenv("FOSVOS_THREADS")) return {pick, atoi(e), 1};
+    if (const char *e = lab_env("FOSVOS_THREADS")) return {pick, atoi(e), 1};
 #endif
     // (measured: at 2028 waves - 32 -> 32 channels on 135 x 240 - four slices cost 20 us against 15 unsliced; at 512 waves -
     // 128 -> 128 on 34 x 60 - eight slices take 32 us against 83)

@@ -142,7 +142,7 @@ int forward_impl(hipEvent_t *ev, const fosvos_vgg_weights *w, const float *frame
     // of 512 workgroups, conv4 2.2) and what one chain's workgroups spend outside their chunk loops.  +1.0 % on the step.
     // Without an auxiliary stream the same two chains run one after the other (the arithmetic of a pass - tile plans, split-K -
     // does not depend on how it is scheduled).  FOSVOS_FWD_SPLIT=0 (lab switch): one chain of N frames.
-    static const bool split_on = !(getenv("FOSVOS_FWD_SPLIT") && atoi(getenv("FOSVOS_FWD_SPLIT")) == 0);
+    static const bool split_on = lab_env_int("FOSVOS_FWD_SPLIT", 1) != 0;
     if (split_on && N >= 2) {
         const int na = (N + 1) / 2;
         if (par) {
@@ -192,7 +192,7 @@ int forward_impl(hipEvent_t *ev, const fosvos_vgg_weights *w, const float *frame
         }
         // each chain runs the head for its own frames (the head is per frame), so the first chain's head runs beside the
         // second chain's last convs instead of behind them
-        static const bool head_per_chain = !(getenv("FOSVOS_HEAD_PER_CHAIN") && atoi(getenv("FOSVOS_HEAD_PER_CHAIN")) == 0);
+        static const bool head_per_chain = lab_env_int("FOSVOS_HEAD_PER_CHAIN", 1) != 0;
         if (head_per_chain) {
             for (int half = 0; half < 2; ++half) {
                 const int f0 = half ? na : 0, nf = half ? N - na : na;
@@ -308,12 +308,12 @@ extern "C" int fosvos_vgg_backward(fosvos_ctx *ctx, const fosvos_vgg_weights *w,
     const bool buckets = g->bucket_events != 0;
     // the weight gradients of stages 1-2 come last; after the cycle's LAST backward pass nothing runs beside them
     const bool tail = g->last_pass_of_cycle != 0;
-    static const int tail_stages = getenv("FOSVOS_TAIL_STAGES") ? atoi(getenv("FOSVOS_TAIL_STAGES")) : 1;  // lab switch
+    static const int tail_stages = lab_env_int("FOSVOS_TAIL_STAGES", 1);  // lab switch
     // In the cycle's last pass the data-gradient stream runs dry while the weight-gradient stream still owes stages 2-1
     // (timeline: ~300 us with the chip a quarter full).  Two pieces of that tail need nothing the wgrad stream has not
     // long finished, and move to the main stream's end: conv1_1's weight gradient (its operands are the main stream's own
     // last outputs) and the slab reduction of stage 2 (behind an event the wgrad stream records after stage 2's kernels).
-    static const bool offload_on = !(getenv("FOSVOS_TAIL_OFFLOAD") && atoi(getenv("FOSVOS_TAIL_OFFLOAD")) == 0);
+    static const bool offload_on = lab_env_int("FOSVOS_TAIL_OFFLOAD", 1) != 0;
     const bool offload = tail && aux_stream != nullptr && aux_stream != stream && offload_on;
     FOSVOS_ENTER(device);
     ctx->buckets_recorded = false;

@@ -12,10 +12,12 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint,
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
+# FOSVOS_HIP_LIB: another build of the same ABI (the lab build `make -C fosvos_amd/csrc lab`, whose FOSVOS_* switches the shipped
+# library does not read); bench.py records every FOSVOS_* variable of the process in its JSON line
+LIB_PATH = os.environ.get("FOSVOS_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 CONV_RELU = 1
 CONV_OUT_F32 = 2
 
@@ -49,7 +51,8 @@ class VggGrads(ctypes.Structure):
 
 class Conv3x3PlanInfo(ctypes.Structure):
     """fosvos_conv3x3_plan_info."""
-    _fields_ = [("tile_h", c_int), ("tile_w", c_int), ("tile_co", c_int), ("k_splits", c_int), ("workgroups", c_int)]
+    _fields_ = [("tile_h", c_int), ("tile_w", c_int), ("tile_co", c_int), ("k_splits", c_int), ("workgroups", c_int),
+                ("persistent", c_int)]
 
 
 class ProfileRecord(ctypes.Structure):
@@ -91,6 +94,7 @@ SIGNATURES = {
     "fosvos_ctx_destroy": (c_int, [c_void_p]),
     "fosvos_ctx_device": (c_int, [c_void_p]),
     "fosvos_conv3x3_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(Conv3x3PlanInfo)]),
+    "fosvos_conv3x3_fwd_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, POINTER(Conv3x3PlanInfo)]),
     "fosvos_conv3x3_first_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "fosvos_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fosvos_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

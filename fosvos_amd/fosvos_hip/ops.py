@@ -224,13 +224,25 @@ def conv3x3_first_wgrad(frame: torch.Tensor, dy: torch.Tensor) -> Tuple[torch.Te
 
 
 def conv3x3_plan(n: int, h: int, w: int, in_ch: int, out_ch: int) -> dict:
-    """The igemm instantiation fosvos_conv3x3_fwd / _fwd_pool / _dgrad launch for this shape (host arithmetic only):
-    {"tile": (tile_h, tile_w, tile_co), "k_splits", "workgroups"}."""
+    """The igemm instantiation fosvos_conv3x3_dgrad (and the forward forms the persistent kernel does not take) launch for
+    this shape (host arithmetic only): {"tile": (tile_h, tile_w, tile_co), "k_splits", "workgroups", "persistent"}."""
     import ctypes
     from . import Conv3x3PlanInfo
     info = Conv3x3PlanInfo()
     check(lib().fosvos_conv3x3_plan(n, h, w, in_ch, out_ch, ctypes.byref(info)), "conv3x3_plan")
-    return {"tile": (info.tile_h, info.tile_w, info.tile_co), "k_splits": info.k_splits, "workgroups": info.workgroups}
+    return {"tile": (info.tile_h, info.tile_w, info.tile_co), "k_splits": info.k_splits, "workgroups": info.workgroups,
+            "persistent": bool(info.persistent)}
+
+
+def conv3x3_fwd_plan(n: int, h: int, w: int, in_ch: int, out_ch: int, relu: bool = True) -> dict:
+    """What fosvos_conv3x3_fwd / _fwd_pool launch for a bf16-output forward conv of this shape: the persistent eight-wave
+    kernel k_conv3x3_pp ("persistent": True, 256 workgroups) where its tiles fill the chip, else the igemm instantiation."""
+    import ctypes
+    from . import Conv3x3PlanInfo
+    info = Conv3x3PlanInfo()
+    check(lib().fosvos_conv3x3_fwd_plan(n, h, w, in_ch, out_ch, CONV_RELU if relu else 0, ctypes.byref(info)), "conv3x3_fwd_plan")
+    return {"tile": (info.tile_h, info.tile_w, info.tile_co), "k_splits": info.k_splits, "workgroups": info.workgroups,
+            "persistent": bool(info.persistent)}
 
 
 def conv3x3_first_plan(n: int, h: int, w: int) -> Tuple[int, int]:

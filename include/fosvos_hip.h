@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 12
+#define FOSVOS_ABI_VERSION 13
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -176,8 +176,15 @@ typedef struct fosvos_conv3x3_plan_info {
     int tile_h, tile_w, tile_co;
     int k_splits;
     int workgroups; /* per K split */
+    int persistent; /* 1: the persistent eight-wave forward kernel k_conv3x3_pp (conv_pp.hip): `workgroups` of them, one per
+                     * CU, walk the 8 x 32-pixel x 64-channel tiles in two groups of four waves that alternate between the
+                     * MFMAs of a K chunk and the memory work of the other tile */
 } fosvos_conv3x3_plan_info;
 int fosvos_conv3x3_plan(int N, int H, int W, int in_ch, int out_ch, fosvos_conv3x3_plan_info *out);
+/* The same question for a FORWARD launch (fosvos_conv3x3_fwd / _fwd_pool with these flags): bf16-output launches whose
+ * tiles fill the chip run the persistent kernel; every other form (data gradient, residual add, stride 2, fp32 output) is
+ * what fosvos_conv3x3_plan reports. */
+int fosvos_conv3x3_fwd_plan(int N, int H, int W, int in_ch, int out_ch, unsigned flags, fosvos_conv3x3_plan_info *out);
 /* dx = mask( dgrad(dy) ) + addend:  the same kernel run on the rotated/transposed filter image.
  *   dy       bf16 NHWC, Co_pad = roundup(Co,32) channels (Co = the forward op's OUTPUT channels)
  *   relu_src bf16 NHWC [N,H,W,Ci] or NULL: where relu_src <= 0 the computed gradient is zeroed

@@ -305,11 +305,58 @@ def _assert_tile(ops, n, h, w, in_ch, out_ch, tile):
     assert plan["workgroups"] >= 256
 
 
+# ------------------------------------------------------------------------------------------ the persistent forward kernel
+# k_conv3x3_pp (csrc/conv_pp.hip): 256 persistent workgroups of two four-wave groups.  The cases cover: both K-chunk regimes
+# (<= 64 input channels: the weight chunks stay in LDS; more: the double-buffered reload), 1 / 2 / 4 / 8 channel blocks per
+# XCD, tile counts that leave group 1 of some workgroups without a last tile, ragged right / bottom edges, odd H and W
+# (ragged pooling windows), several images per launch.  Each asserts through fosvos_conv3x3_fwd_plan that the launch IS the
+# persistent kernel.
+PP_CASES = [
+    # n, h, w, ci, co
+    (1, 480, 854, 64, 64),     # conv1_2 of one frame: 1620 tiles (3.2 rounds: the last round leaves groups without a tile), 854 = 26 * 32 + 22
+    (2, 240, 427, 64, 128),    # conv2_1: two channel blocks, 427 = 13 * 32 + 11
+    (3, 240, 427, 128, 128),   # four K chunks: the weight chunks are reloaded every super-step
+    (4, 60, 107, 256, 256),    # eight K chunks, four channel blocks, exactly one tile per group, bottom tiles half outside (60 = 7 * 8 + 4)
+    (2, 60, 107, 256, 512),    # eight channel blocks
+    (6, 121, 213, 64, 64),     # odd H and W: the last pooling row / column windows hold one pixel row / column
+    (7, 97, 335, 96, 64),      # three K chunks (odd count: chunk index and buffer parity drift apart)
+]
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", PP_CASES)
+def test_conv3x3_fwd_persistent(ops, n, h, w, ci, co):
+    """Forward conv + bias + ReLU on the persistent kernel, whole tensors against torch fp32 on identically rounded inputs;
+    the same launch with the fused ceil-mode pool: y bit-identical, pooled map exactly the pool of y; the linear form (no
+    bias, no ReLU); a second launch bit-identical (fixed summation order)."""
+    plan = ops.conv3x3_fwd_plan(n, h, w, ci, co)
+    assert plan["persistent"] and plan["tile"] == (8, 32, 64) and plan["workgroups"] == 256, plan
+    x = bf(gen(n, ci, h, w, seed=150))
+    wt = gen(co, ci, 3, 3, seed=151, scale=math.sqrt(2.0 / (9 * ci)))
+    b = gen(co, seed=152, scale=0.2)
+    ref = F.relu(F.conv2d(x, bf(wt), b, padding=1))
+    wf, _ = ops.pack_conv3x3_weights(wt.to(DEV))
+    xd = to_nhwc_bf16(x)
+    y = ops.conv3x3_fwd(xd, wf, b.to(DEV), ci, co, relu=True)
+    assert_bf16_close(from_nhwc(y), ref, f"conv3x3 persistent fwd {n}x{h}x{w} {ci}->{co}")
+    y2, yp = ops.conv3x3_fwd_pool(xd, wf, b.to(DEV), ci, co, relu=True)
+    assert torch.equal(y2, y)
+    assert yp.shape == (n, (h + 1) // 2, (w + 1) // 2, co)
+    assert torch.equal(from_nhwc(yp), F.max_pool2d(from_nhwc(y), 2, 2, ceil_mode=True))
+    assert ops.conv3x3_fwd_plan(n, h, w, ci, co, relu=False)["persistent"]
+    y3 = ops.conv3x3_fwd(xd, wf, None, ci, co, relu=False)
+    assert_bf16_close(from_nhwc(y3), F.conv2d(x, bf(wt), None, padding=1), "conv3x3 persistent fwd linear")
+    assert torch.equal(ops.conv3x3_fwd(xd, wf, b.to(DEV), ci, co, relu=True), y)
+
+
 @pytest.mark.parametrize("n,h,w,ci,co,tile", HOT_CASES)
 def test_conv3x3_fwd_hot_tiles(ops, n, h, w, ci, co, tile):
     """Forward conv + bias + ReLU on the 256-pixel tiles, whole tensors against torch fp32 on identically rounded inputs;
-    the same launch with the fused ceil-mode pool: y bit-identical, pooled map exactly the pool of y."""
-    _assert_tile(ops, n, h, w, ci, co, tile)
+    the same launch with the fused ceil-mode pool: y bit-identical, pooled map exactly the pool of y.  (Where the forward
+    entry point now takes the persistent kernel for this shape, this test covers that; the igemm tiles stay covered by the
+    data-gradient tests below, which run the same instantiations.)"""
+    fplan = ops.conv3x3_fwd_plan(n, h, w, ci, co)
+    if not fplan["persistent"]:
+        _assert_tile(ops, n, h, w, ci, co, tile)
     x = bf(gen(n, ci, h, w, seed=110))
     wt = gen(co, ci, 3, 3, seed=111, scale=math.sqrt(2.0 / (9 * ci)))
     b = gen(co, seed=112, scale=0.2)
