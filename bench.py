@@ -62,7 +62,9 @@ AVG_GRAD_EVERY_N = 5
 # device that is still raising its clocks after the idle start-up of the process (FOSVOS_BENCH_PRECONDITION=0 turns it off)
 PRECONDITION_STEPS = int(os.environ.get("FOSVOS_BENCH_PRECONDITION", "70"))
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
-CONV_KERNEL_PREFIXES = ("k_conv3x3_igemm", "k_wgrad3x3", "k_wgrad_first")  # the MFMA kernels the roofline object is about
+# the MFMA kernels the roofline object is about (forward: persistent k_conv3x3_pp or k_conv3x3_igemm; data gradient:
+# k_conv3x3_igemm; weight gradient: k_wgrad3x3_v2, k_wgrad_first)
+CONV_KERNEL_PREFIXES = ("k_conv3x3_igemm", "k_conv3x3_pp", "k_wgrad3x3", "k_wgrad_first")
 
 
 def parse():
@@ -364,6 +366,7 @@ def main():
                 else:
                     os.environ[k] = v
         host_lead[mode] = ret.get("seconds_host_enqueue")
+        comm_timing[mode] = ret.get("comm_timing")
         if world > 1:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -371,6 +374,8 @@ def main():
         train_online.data_parallel = False
         return elapsed, prov, opt, run
 
+    comm_timing = {}  # per data-parallel mode: parallel.GradSync.timing_summary() of the timed steps
+    parallel.COMM_TIMING = world > 1
     host_lead = {}  # per mode: seconds the host loop needed to ENQUEUE the timed steps (the device finishes later)
     modes = ["single"] if world == 1 else (["dp", "dp_strict", "replicas"] if args.mode == "both" else [args.mode])
     results = {}
@@ -423,18 +428,50 @@ def main():
             "parallelism": parallelism(head),
         },
     }
+    # every FOSVOS_* variable of this process (lab switches of the Python side; the shipped library itself reads none)
+    out["env_overrides"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("FOSVOS_")}
+    if comm_timing.get(head):
+        out["comm"] = comm_timing[head]
+        out["comm_exposed_ms_per_step"] = comm_timing[head]["comm_exposed_ms_per_step"]
     for m in modes[1:]:
         e = results[m][0]
         out[m] = {"value": args.steps * world / e, "unit": "frames/s", "ms_per_step": e / args.steps * 1000.0,
                   "parallelism": parallelism(m)}
+        if comm_timing.get(m):
+            out[m]["comm"] = comm_timing[m]
+            out[m]["comm_exposed_ms_per_step"] = comm_timing[m]["comm_exposed_ms_per_step"]
+    if world > 1 and "replicas" in results:
+        # BASELINE configs[3] as the reference runs it (src/train_online.py:178-189: one sequence per process, no collective)
+        out["replicas"]["parity_preserving"] = True
+        out["cfg3_headline"] = {"replicas": out["replicas"]["value"] if head != "replicas" else out["value"],
+                                "dp": out["value"] if head == "dp" else out.get("dp", {}).get("value"),
+                                "unit": "frames/s",
+                                "note": "replicas = the reference's own multi-device mapping (independent sequences, results "
+                                        "identical to one GPU); dp = weak scaling with 5 micro-batches per rank and step"}
     if cold is not None:
         out["cold"] = {"value": args.steps / cold, "unit": "frames/s", "ms_per_step": cold / args.steps * 1000.0,
                        "note": f"the same {args.steps} steps behind {args.warmup} warm-up steps only, timed first (no preconditioning)"}
+    if world == 1 and not args.no_variants and want("steps100") and args.steps != 100:
+        # this file's default window (100 steps, 20 warm-up) beside the driver's --steps 20 --warmup 5: the same loop, the
+        # per-call costs of a short window (0.25 ms of host set-up and tail) amortised
+        saved_steps, saved_warm = args.steps, args.warmup
+        args.steps, args.warmup = 100, 20
+        try:
+            e = timed("steps100")[0]
+        finally:
+            args.steps, args.warmup = saved_steps, saved_warm
+        out["steps100"] = {"value": 100 / e, "unit": "frames/s", "ms_per_step": e / 100 * 1000.0, "steps": 100, "warmup": 20}
     if world == 1 and not args.no_variants and want("group1"):
         # one frame per pass: the reference's own order, and the worst case of the shape bucketing
         e = timed("group1", env={"FOSVOS_MICROBATCH_GROUP": "1"})[0]
+        probe = {role: _engine.STREAM_PROBE.get((dev_index, role)) for role in ("aux", "pass")}
         out["group1"] = {"value": args.steps / e, "unit": "frames/s", "ms_per_step": e / args.steps * 1000.0,
-                         "note": "FOSVOS_MICROBATCH_GROUP=1: every micro-batch its own forward / backward pass"}
+                         "note": "FOSVOS_MICROBATCH_GROUP=1: every micro-batch its own forward / backward pass",
+                         # measured when the streams were created (engine.shared_stream): do the pass stream and the
+                         # weight-gradient stream run beside the caller's stream and beside each other?
+                         "pass_streams_overlap": (probe["pass"] or {}).get("overlaps_with"),
+                         "aux_stream_overlap": (probe["aux"] or {}).get("overlaps_with"),
+                         "stream_probe": probe}
     if world == 1 and not args.no_variants and want("mixed_scales"):
         # the reference's augmentation: a random scale per iteration, fixed seed; 20 frames per epoch
         import random
@@ -468,6 +505,54 @@ def main():
                                "note": "frames drawn from {1.0, 0.8, 0.5} x 480x854 (seed 1234, 20 per epoch), bucketed by "
                                        "shape inside each accumulation cycle of 5 (src/dataloaders/custom_transforms.py:63-76)"}
         del mixed
+    if world == 1 and not args.no_variants and want("davis_tree"):
+        # The training half of train_and_test on a DAVIS-shaped tree ON DISK (one sequence, 480x854 JPEG + PNG mask written
+        # here): the loader the script itself builds - io_helper.get_data_loader_train(root, 1, seq) - feeds _train, so the
+        # rate INCLUDES the loader: the one-shot sample's six flip / scale variants resident on the device, drawn per epoch
+        # with the reference pipeline's random numbers (dataloaders/resident.py).  `per_iteration_pipeline` = the same
+        # loop behind the reference's own arrangement (DataLoader, one worker start + decode + resample per iteration).
+        import tempfile
+        import numpy as np
+        from PIL import Image
+        from util import io_helper
+        root = tempfile.mkdtemp(prefix="fosvos_davis_")
+        for sub in ("JPEGImages/480p/bench", "Annotations/480p/bench", "ImageSets/480p"):
+            os.makedirs(os.path.join(root, sub))
+        rs = np.random.RandomState(1234)
+        yy, xx = np.mgrid[0:H, 0:W]
+        lines = []
+        for kf in range(2):
+            m = (((yy - 0.45 * H) / (0.2 * H)) ** 2 + ((xx - (0.5 + 0.02 * kf) * W) / (0.16 * W)) ** 2 <= 1.0)
+            fr = (rs.randint(0, 150, size=(H, W, 3)) + 100 * m[:, :, None]).astype(np.uint8)
+            Image.fromarray(fr).save(os.path.join(root, "JPEGImages/480p/bench/%05d.jpg" % kf), quality=95)
+            Image.fromarray((m * 255).astype(np.uint8)).save(os.path.join(root, "Annotations/480p/bench/%05d.png" % kf))
+            lines.append("/JPEGImages/480p/bench/%05d.jpg /Annotations/480p/bench/%05d.png\n" % (kf, kf))
+        for split in ("train", "val", "trainval"):
+            with open(os.path.join(root, "ImageSets/480p", split + ".txt"), "w") as f:
+                f.write("".join(lines))
+        torch.manual_seed(1234)
+        t0 = time.perf_counter()
+        res_loader = io_helper.get_data_loader_train(root, 1, "bench")
+        build_s = time.perf_counter() - t0
+        saved_steps, saved_warm = args.steps, args.warmup
+        args.steps, args.warmup = 100, 20
+        try:
+            e = timed("davis_tree", precondition=40, loader=res_loader)[0]
+            draws = list(res_loader.draws[-100:])
+            args.steps, args.warmup = 10, 2
+            e_pipe = timed("davis_pipeline", precondition=0, loader=io_helper.get_data_loader_train(root, 1, "bench", resident=False))[0]
+        finally:
+            args.steps, args.warmup = saved_steps, saved_warm
+        px = sum(res_loader.variants[d]["image"].shape[2] * res_loader.variants[d]["image"].shape[3] for d in draws) / len(draws)
+        out["davis_tree"] = {"value": 100 / e, "unit": "frames/s", "ms_per_step": e / 100 * 1000.0, "steps": 100,
+                             "loader": type(res_loader).__name__, "loader_build_s": build_s,
+                             "mean_pixels_per_frame": px, "full_frame_equivalents_per_s": 100 / e * px / (H * W),
+                             "per_iteration_pipeline": {"value": 10 / e_pipe, "unit": "frames/s", "steps": 10,
+                                                        "ms_per_step": e_pipe / 10 * 1000.0},
+                             "note": "train_online._train fed by the loader train_and_test builds for a sequence run on a "
+                                     "DAVIS tree on disk (src/util/io_helper.py:62-70, src/dataloaders/davis_2016.py:72-83)"}
+        import shutil
+        shutil.rmtree(root, ignore_errors=True)
     if world == 1 and not args.no_variants and want("offline"):
         out["offline"] = offline_config(args, dev, make_frame, barrier)
 
@@ -492,37 +577,44 @@ def main():
         conv_calls = sum(a["launches"] for a in conv) / n_prof
         conv_flop = sum(a["flops"] for a in conv) / n_prof
         fam_achieved = conv_flop / (conv_ms * 1e-3) / 1e12
-        # the dominant kernel: the MFMA kernel template (all its instantiations) with the most time per step
+        # The dominant kernel = the single kernel NAME (one instantiation, as rocprofv3 prints it) with the most time per step:
+        # its time per step cannot exceed the step, whatever overlaps with it.  Beside it: `template` (all instantiations of
+        # the kernel template with the most time per step - what this field carried in round 3), `family` (all conv MFMA
+        # kernels), `alone`, `step_wall_frac`.
+        dom_name, dom = max(((k, a) for k, a in prof.records.items() if k.startswith(CONV_KERNEL_PREFIXES)),
+                            key=lambda kv: kv[1]["ms"])
+        achieved = dom["flops"] / dom["ms"] / 1e9
         groups = {}
         for k, a in prof.records.items():
             if k.startswith(CONV_KERNEL_PREFIXES):
                 g = groups.setdefault(k.split("<")[0], {"ms": 0.0, "flops": 0.0, "launches": 0, "names": []})
                 g["ms"] += a["ms"]; g["flops"] += a["flops"]; g["launches"] += a["launches"]; g["names"].append(k)
-        dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
-        achieved = dom["flops"] / dom["ms"] / 1e9
+        tpl_name, tpl = max(groups.items(), key=lambda kv: kv[1]["ms"])
         # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process); null when no
         # summary is present or the kernel is not in it
-        traffic, fam_traffic, traffic_note = None, None, "no profiles/*_pmc_traffic.json present"
+        traffic, tpl_traffic, fam_traffic, traffic_note = None, None, None, "no profiles/*_pmc_traffic.json present"
         try:
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
             if cands:
                 pm = json.load(open(cands[-1]))
                 fam_traffic = pm["summary"]["conv_mfma_family"]["hbm_bytes_per_launch"]
-                tb, tl = 0.0, 0
-                for k, v in pm.get("per_kernel", {}).items():
-                    if any(k.endswith(n) for n in dom["names"]):
-                        tb += (v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]) * v["launches"]
-                        tl += v["launches"]
-                traffic = tb / tl if tl else None
-                traffic_note = (f"HBM bytes/launch of this kernel (family: all conv MFMA kernels) from "
-                                f"{os.path.relpath(cands[-1], ROOT)}: {pm['source']}; {pm['corrections']}")
+
+                def per_launch(names):
+                    tb, tl = 0.0, 0
+                    for k, v in pm.get("per_kernel", {}).items():
+                        if any(k.endswith(n) for n in names):
+                            tb += (v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]) * v["launches"]
+                            tl += v["launches"]
+                    return tb / tl if tl else None
+                traffic, tpl_traffic = per_launch([dom_name]), per_launch(tpl["names"])
+                traffic_note = (f"HBM bytes/launch of this kernel from {os.path.relpath(cands[-1], ROOT)}: {pm['source']}; "
+                                f"{pm['corrections']}")
         except Exception as e:  # a malformed summary must not break the bench line
             traffic_note = f"could not read PMC summary: {e}"
         out["roofline"] = {
             "bound": "mfma",
-            "kernel": dom_name + " (the MFMA kernel template with the most time per step, all its instantiations: "
-                      + ", ".join(sorted(n[len(dom_name):] for n in dom["names"])) + "; bf16 operands, fp32 accumulate)",
+            "kernel": dom_name + " (the kernel with the most time per step; bf16 operands, fp32 accumulate)",
             "achieved": achieved,
             "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s",
@@ -535,14 +627,22 @@ def main():
                         f"stream, so a kernel's duration is that of a kernel sharing the chip; `alone` = the same kernels with "
                         f"the chip to themselves, `step_wall_frac` = the step's FLOPs over its wall time",
             "launches_per_step": dom["launches"] / n_prof,
+            "ms_per_step": dom["ms"] / n_prof,
             "algorithmic_gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
             "avg_launch_us": dom["ms"] / dom["launches"] * 1000.0,
-            # all conv MFMA kernels together (k_conv3x3_igemm forward + data gradient, k_wgrad3x3 / k_wgrad_first): the
-            # figure `roofline.achieved` carried until round 3
+            # the kernel TEMPLATE with the most time per step, all its instantiations (their launches overlap each other, so
+            # this sum may exceed the step)
+            "template": {"kernel": tpl_name, "instantiations": sorted(n[len(tpl_name):] for n in tpl["names"]),
+                         "achieved": tpl["flops"] / tpl["ms"] / 1e9, "frac": tpl["flops"] / tpl["ms"] / 1e9 / MFMA_BF16_PEAK_TFLOPS,
+                         "launches_per_step": tpl["launches"] / n_prof, "ms_per_step": tpl["ms"] / n_prof,
+                         "avg_launch_us": tpl["ms"] / tpl["launches"] * 1000.0, "traffic": tpl_traffic},
+            # all conv MFMA kernels together
             "family": {"achieved": fam_achieved, "frac": fam_achieved / MFMA_BF16_PEAK_TFLOPS,
                        "launches_per_step": conv_calls, "algorithmic_gflop_per_step": conv_flop / 1e9,
                        "avg_launch_us": conv_ms / conv_calls * 1000.0, "traffic": fam_traffic},
             "device_ms_per_step_all_kernels": sum(a["ms"] for a in prof.records.values()) / n_prof,
+            "non_mfma_ms_per_step": sum(a["ms"] for k, a in prof.records.items() if not k.startswith(CONV_KERNEL_PREFIXES)) / n_prof,
+            "launches_per_step_all_kernels": sum(a["launches"] for a in prof.records.values()) / n_prof,
             # the same FLOPs over the WALL time of a step of the timed region (everything included: the streams overlap,
             # so the kernel durations above add up to more than the step; the non-MFMA kernels, launch gaps and the optimizer
             # step are in it too): what the whole step sustains, next to what its kernels sustain while they run

@@ -290,6 +290,32 @@ _CONV_NAMES = [(wn, bn) for (_, _, _, _, wn, bn) in CONVS]
 # training call) therefore made the two-stream passes fast or slow by creation order (seen: 1290 vs 950 frames/s for the
 # same loop, depending on what ran earlier in the process).  Fixed streams make the mapping the same for every model.
 _SHARED_STREAMS: Dict[Tuple[int, str], "torch.cuda.Stream"] = {}
+# What the probe below measured when a role's stream was created: {(device, role): {"overlaps_with": {name: bool}, "tries": n,
+# "ms": {...}}}.  bench.py copies it into its JSON line (group1.pass_streams_overlap ...).
+STREAM_PROBE: Dict[Tuple[int, str], dict] = {}
+_PROBE_CYCLES = 400_000  # ~0.2 ms of spinning per kernel
+
+
+def _streams_overlap(device_index: int, a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> Tuple[bool, float, float]:
+    """Do kernels on `a` and `b` run side by side?  Two spin kernels (torch.cuda._sleep), one per stream, timed on the host
+    between device syncs against one spin kernel alone: two streams that share a hardware queue take twice as long as one.
+    Returns (overlap, ms alone, ms of the pair).  Costs ~1 ms, once per pair and process."""
+    import time
+    dev = torch.device("cuda", device_index)
+
+    def run(streams):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(_PROBE_CYCLES)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) * 1e3
+
+    run([a]); run([a, b])  # warm: first launches, clocks
+    alone = min(run([a]) for _ in range(3))
+    pair = min(run([a, b]) for _ in range(3))
+    return pair < 1.5 * alone, alone, pair
 
 
 def shared_stream(device_index: int, role: str) -> "torch.cuda.Stream":
@@ -302,7 +328,34 @@ def shared_stream(device_index: int, role: str) -> "torch.cuda.Stream":
         # lab switch FOSVOS_STREAM_SKIP_<ROLE>=k: k throw-away streams first (shifts the role onto another hardware queue)
         skip = int(os.environ.get("FOSVOS_STREAM_SKIP_" + role.upper(), "0") or 0)
         _SHARED_STREAMS[("skipped", role, device_index)] = [torch.cuda.Stream(device=device_index) for _ in range(skip)]
-        st = _SHARED_STREAMS[key] = torch.cuda.Stream(device=device_index)
+        # The mapping is MEASURED, not trusted: the new stream must overlap with the caller's stream and with every role
+        # created before it (the weight-gradient stream beside the data-gradient chain; the pass stream beside both).  If the
+        # probe finds the pair serialised, the stream is parked (it keeps its queue slot) and the next one is tried.
+        others = {"caller": torch.cuda.current_stream(device_index)}
+        for r in order:
+            if (device_index, r) in _SHARED_STREAMS:
+                others[r] = _SHARED_STREAMS[(device_index, r)]
+        probe_on = os.environ.get("FOSVOS_STREAM_PROBE", "1") != "0" and role != "comm" and hasattr(torch.cuda, "_sleep")
+        parked, result = [], {"overlaps_with": {}, "tries": 0, "ms": {}}
+        for attempt in range(6):
+            st = torch.cuda.Stream(device=device_index)
+            result["tries"] = attempt + 1
+            if not probe_on:
+                break
+            ok = True
+            for name, other in others.items():
+                if other.cuda_stream == st.cuda_stream:
+                    continue
+                good, alone, pair = _streams_overlap(device_index, other, st)
+                result["overlaps_with"][name] = bool(good)
+                result["ms"][name] = [round(alone, 3), round(pair, 3)]
+                ok = ok and good
+            if ok:
+                break
+            parked.append(st)
+        _SHARED_STREAMS[("parked", role, device_index)] = parked
+        STREAM_PROBE[key] = result
+        _SHARED_STREAMS[key] = st
     return st
 
 

@@ -208,7 +208,8 @@ class FlatGrads:
             return None
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
 
-    def all_reduce_begin(self, wait_bucket: Optional[Callable[[int], None]] = None) -> None:
+    def all_reduce_begin(self, wait_bucket: Optional[Callable[[int], None]] = None,
+                         on_bucket: Optional[Callable[[int, object], None]] = None) -> None:
         """One asynchronous SUM all-reduce per slice, in completion order.  `wait_bucket(id)` is called right before a
         slice's collective is enqueued with the slice's NATIVE bucket id (`bucket_ids`) and must make the CURRENT stream
         wait for that bucket's gradients (on the HIP path: fosvos_vgg_grad_bucket_wait on the communication stream);
@@ -218,7 +219,11 @@ class FlatGrads:
         for b, (lo, hi) in enumerate(self.slices):
             if wait_bucket is not None:
                 wait_bucket(self.bucket_ids[b])
+            if on_bucket is not None:
+                on_bucket(b, None)  # (timing: an event in front of the collective)
             self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            if on_bucket is not None:
+                on_bucket(b, self._works[-1])
 
     def all_reduce_wait(self, bucket: int) -> None:
         """Make the current stream (the host, for CPU tensors) wait for bucket `bucket`'s collective of all_reduce_begin
@@ -233,6 +238,9 @@ class FlatGrads:
             if w is not None:
                 w.wait()
         self._works = []
+
+
+COMM_TIMING = False  # bench.py sets it for its data-parallel runs
 
 
 class GradSync:
@@ -252,6 +260,12 @@ class GradSync:
         self.net, self.flat = net, flat
         self.active = world_size() > 1
         self._comm = None
+        # Communication timing (COMM_TIMING / FOSVOS_COMM_TIMING=1; GPU only): per optimizer step, events on the
+        # communication stream in front of and behind every bucket's all-reduce, an event on the main stream where the data-
+        # gradient chain of the cycle's last backward pass ended, and one where the optimizer step is ready to start: what
+        # timing_summary() turns into per-bucket offsets and the exposed communication time per step.
+        self.timing = COMM_TIMING or os.environ.get("FOSVOS_COMM_TIMING", "0") == "1"
+        self._steps: list = []   # per step: {"dgrad_end": ev, "ready": ev, "buckets": [(start ev, end ev, bytes)]}
 
     def arm(self) -> None:
         if self.active and hasattr(self.net, "publish_grad_buckets"):
@@ -277,8 +291,25 @@ class GradSync:
                 if b >= VGG_EARLY_BUCKETS:  # the tail buckets also hold gradients the host side adds on the main stream (score_dsn)
                     comm.wait_stream(main)
 
+            on_bucket = None
+            if self.timing:
+                rec = {"dgrad_end": torch.cuda.Event(enable_timing=True), "ready": None, "buckets": []}
+                rec["dgrad_end"].record(main)  # (the backward call has returned: its data-gradient chain ends here on `main`)
+                self._steps.append(rec)
+                slices = self.flat.slices
+
+                def on_bucket(b: int, work) -> None:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    if work is None:
+                        ev.record(comm)
+                        rec["buckets"].append([ev, None, (slices[b][1] - slices[b][0]) * 4])
+                    else:
+                        work.wait()  # the communication stream itself waits for the collective, so that the event is behind it
+                        ev.record(comm)
+                        rec["buckets"][-1][1] = ev
+
             with torch.cuda.stream(comm):
-                self.flat.all_reduce_begin(wait)
+                self.flat.all_reduce_begin(wait, on_bucket)
         elif self.flat.flat.is_cuda:  # no per-bucket events: the communication stream follows the whole backward pass
             if self._comm is None:
                 self._comm = torch.cuda.Stream(device=self.flat.flat.device)
@@ -297,4 +328,31 @@ class GradSync:
 
     def finish(self) -> None:
         if self.active:
+            if self.timing and self._steps and self._steps[-1]["ready"] is None and self.flat.flat.is_cuda:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(self.flat.flat.device))  # here the optimizer step could start
+                self._steps[-1]["ready"] = ev
             self.flat.all_reduce_finish()
+
+    def timing_summary(self) -> Optional[dict]:
+        """After a device sync: per bucket the mean start / end of its all-reduce in ms after the end of the data-gradient
+        chain, its bytes, and `comm_exposed_ms_per_step` = how long after the optimizer step was ready the last bucket
+        ended (0 when the communication hid behind the rest of the backward pass)."""
+        steps = [r for r in self._steps if r["ready"] is not None and r["buckets"] and all(b[1] is not None for b in r["buckets"])]
+        if not steps:
+            return None
+        n_b = len(steps[0]["buckets"])
+        start = [0.0] * n_b
+        end = [0.0] * n_b
+        exposed = 0.0
+        for r in steps:
+            for i, (e0, e1, _) in enumerate(r["buckets"]):
+                start[i] += r["dgrad_end"].elapsed_time(e0)
+                end[i] += r["dgrad_end"].elapsed_time(e1)
+            exposed += max(0.0, r["ready"].elapsed_time(r["buckets"][-1][1]))
+        n = len(steps)
+        return {"optimizer_steps": n, "comm_exposed_ms_per_step": exposed / n,
+                "buckets": [{"bytes": steps[0]["buckets"][i][2], "start_ms_after_dgrad_end": start[i] / n,
+                             "end_ms_after_dgrad_end": end[i] / n} for i in range(n_b)],
+                "note": "events on the communication stream around every bucket's all-reduce, relative to the end of the "
+                        "data-gradient chain of the cycle's last backward pass (negative = under the backward pass)"}

@@ -426,7 +426,8 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     log.info('Train {0}: total time {1} sec'.format(seq_name, str(time_for_all)))
     log.info('Train {0}: {1} images'.format(seq_name, str(n_images)))
     log.info('Train {0}: time per sample {1} sec'.format(seq_name, str(time_for_all / max(n_images, 1))))
-    return {'loss': loss_tr, 'seconds': time_for_all, 'iterations': n_iters, 'seconds_host_enqueue': time_enqueued}
+    return {'loss': loss_tr, 'seconds': time_for_all, 'iterations': n_iters, 'seconds_host_enqueue': time_enqueued,
+            'comm_timing': sync.timing_summary() if sync.active and sync.timing else None}
 
 
 def main(argv=None):

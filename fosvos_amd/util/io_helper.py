@@ -46,9 +46,13 @@ def write_settings(save_dir: Path, name: str, settings, variant_offline: Optiona
 
 def get_data_loader_train(db_root_dir, batch_size: int, seq_name: Optional[str] = None,
                           synthetic: Optional[Tuple[int, int]] = None,
-                          shard: Optional[Tuple[int, int]] = None) -> DataLoader:
+                          shard: Optional[Tuple[int, int]] = None, resident: bool = True) -> DataLoader:
     """shard = (rank, world): this process draws its own 1/world of every epoch (data-parallel OFFLINE training, where
-    the ranks split each iteration's batch); None: the reference's single-process loader."""
+    the ranks split each iteration's batch); None: the reference's single-process loader.
+    resident: a sequence run (``seq_name``: ONE training sample, src/dataloaders/davis_2016.py:72-83) gets the loader that
+    keeps the sample's six flip / scale variants on the device and draws them with the reference pipeline's random numbers
+    (dataloaders/resident.py: same tensors, same order as the DataLoader below under the same torch seed); False: that
+    DataLoader itself (one worker start + decode + resample per iteration)."""
     if synthetic is not None:
         ds = SyntheticSequence(seq_name or 'synthetic', synthetic[0], synthetic[1], n_frames=1,
                                seed=1234 + (shard[0] if shard else 0))
@@ -56,6 +60,9 @@ def get_data_loader_train(db_root_dir, batch_size: int, seq_name: Optional[str] 
     # src/util/io_helper.py:62-70: random flip, random rescale (ScaleNRotate stays disabled as in the reference), ToTensor
     composed = custom_transforms.Compose([custom_transforms.RandomHorizontalFlip(), custom_transforms.Resize(),
                                           custom_transforms.ToTensor()])
+    if resident and seq_name is not None and shard is None and batch_size == 1:
+        from dataloaders.resident import ResidentOneShotLoader
+        return ResidentOneShotLoader(DAVIS2016(mode='train', db_root_dir=str(db_root_dir), transform=None, seq_name=seq_name))
     db_train = DAVIS2016(mode='train', db_root_dir=str(db_root_dir), transform=composed, seq_name=seq_name)
     if shard is not None:
         from torch.utils.data.distributed import DistributedSampler

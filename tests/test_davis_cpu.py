@@ -153,7 +153,7 @@ def test_scale_n_rotate_identity_and_quarter_turn():
 def test_training_pipeline_through_the_factories(davis_root):
     from util import io_helper
     random.seed(3)
-    dl = io_helper.get_data_loader_train(davis_root, 1, seq_name="camel")
+    dl = io_helper.get_data_loader_train(davis_root, 1, seq_name="camel", resident=False)  # (the DataLoader itself)
     assert len(dl) == 1
     batch = dl.dataset[0]  # (the factory's worker processes are not needed to check the composed transforms)
     assert batch["image"].dim() == 3 and batch["image"].shape[0] == 3 and batch["gt"].shape[0] == 1
@@ -161,3 +161,37 @@ def test_training_pipeline_through_the_factories(davis_root):
     assert batch["image"].shape[1] in (12, 19, 24)    # scales 0.5 / 0.8 / 1 of 24 rows (cvRound(19.2) = 19)
     te = io_helper.get_data_loader_test(davis_root, 1, seq_name="camel").dataset
     assert len(te) == 2 and te[1]["gt"].sum() == 0
+
+
+def test_resident_one_shot_loader_equals_the_per_iteration_pipeline(davis_root):
+    """A sequence run's training loader (src/util/io_helper.py:62-70 on the ONE sample of src/dataloaders/davis_2016.py:72-83):
+    the device-resident loader (six flip x scale variants built once) against the per-iteration DataLoader (worker process,
+    decode, flip, rescale every epoch) under the same torch seed - the same (shape, flip) sequence and the same tensors, bit
+    for bit, epoch after epoch, and torch's default generator left in the same state."""
+    from util import io_helper
+    from dataloaders.resident import ResidentOneShotLoader
+    n_epochs = 12
+    runs = {}
+    for tag, resident in (("pipeline", False), ("resident", True)):
+        torch.manual_seed(77)
+        loader = io_helper.get_data_loader_train(str(davis_root), 1, "bear", resident=resident)
+        assert isinstance(loader, ResidentOneShotLoader) == resident and len(loader) == 1
+        seen = []
+        for _ in range(n_epochs):
+            batches = list(loader)
+            assert len(batches) == 1
+            seen.append(batches[0])
+        runs[tag] = (seen, torch.rand(3))  # (the generator's state afterwards shows in the next draw)
+    assert torch.equal(runs["pipeline"][1], runs["resident"][1])
+    shapes = set()
+    for a, b in zip(runs["pipeline"][0], runs["resident"][0]):
+        assert a["seq_name"] == b["seq_name"] == ["bear"] and a["fname"] == b["fname"]
+        for key in ("image", "gt"):
+            assert a[key].dtype == b[key].dtype and tuple(a[key].shape) == tuple(b[key].shape), key
+            assert torch.equal(a[key], b[key].cpu()), key
+        shapes.add(tuple(a["image"].shape))
+    assert len(shapes) >= 2  # the scale really changes between epochs under this seed
+    res = io_helper.get_data_loader_train(str(davis_root), 1, "bear")
+    assert len(res.variants) == 6 and {tuple(v["image"].shape[2:]) for v in res.variants.values()} == {(12, 20), (19, 32), (24, 40)}
+    # the whole training set (no sequence) keeps the DataLoader
+    assert not isinstance(io_helper.get_data_loader_train(str(davis_root), 1), ResidentOneShotLoader)

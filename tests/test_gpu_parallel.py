@@ -57,8 +57,9 @@ def _worker(rank, world, port, out_dir):
                       LOCAL_RANK="0")
     import parallel
     assert parallel.init_distributed("gloo")
+    parallel.COMM_TIMING = True  # (the events around every bucket's all-reduce must not change a bit of the result)
     w, _, ret = _train(_frames()[rank::world], True)
-    torch.save({"w": w, "iterations": ret["iterations"]}, os.path.join(out_dir, f"dp{rank}.pt"))
+    torch.save({"w": w, "iterations": ret["iterations"], "comm": ret["comm_timing"]}, os.path.join(out_dir, f"dp{rank}.pt"))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -83,6 +84,13 @@ def test_online_dp_on_gpu_equals_single_process(tmp_path):
                 p.wait()
     res = [torch.load(os.path.join(str(tmp_path), f"dp{r}.pt")) for r in range(2)]
     assert res[0]["iterations"] == res[1]["iterations"] == N_FRAMES // 2
+    # the communication timing of the run (parallel.GradSync.timing_summary): one entry per gradient bucket, every
+    # all-reduce ends after it starts, the sizes add up to the trainable gradients (59.7 MB), two optimizer steps
+    for r in res:
+        comm = r["comm"]
+        assert comm is not None and comm["optimizer_steps"] == 2 and comm["comm_exposed_ms_per_step"] >= 0.0
+        assert 59.0e6 < sum(b["bytes"] for b in comm["buckets"]) < 61.5e6
+        assert all(b["end_ms_after_dgrad_end"] > b["start_ms_after_dgrad_end"] for b in comm["buckets"])
     ref, sd, ret = _train(_frames(), False)
     assert ret["iterations"] == N_FRAMES
     moved = 0
