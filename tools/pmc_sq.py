@@ -10,7 +10,7 @@ def load(path):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
-        if "k_conv3x3_igemm" not in name and "k_wgrad" not in name:
+        if "k_conv3x3_igemm" not in name and "k_wgrad" not in name and "k_conv3x3_pp" not in name:
             continue
         short = name.split("<", 1)[1].split(">(")[0] if "<" in name else name
         key = (short[:40], int(r["Grid_Size"]), int(r["LDS_Block_Size"]), int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]))

@@ -35,6 +35,7 @@ for n in sorted(set(fetch) | set(write)):
     rows[n] = {"launches": calls, "launches_per_step": calls / steps, "hbm_read_bytes_per_launch": fb / calls,
                "hbm_write_bytes_per_launch": wb / calls, "hbm_bytes_per_step": (fb + wb) / steps}
 fam = {"igemm": [k for k in rows if "k_conv3x3_igemm" in k],
+       "pp": [k for k in rows if "k_conv3x3_pp" in k],  # the persistent forward kernel (round 4)
        "wgrad": [k for k in rows if "k_wgrad3x3" in k or "k_wgrad_first" in k],
        "wgrad_reduce": [k for k in rows if "k_wgrad_fold" in k or "k_wgrad_reduce" in k]}
 summary = {}
@@ -43,7 +44,7 @@ for name, ks in fam.items():
     tot = sum(rows[k]["hbm_bytes_per_step"] for k in ks) * steps
     summary[name] = {"launches_per_step": launches / steps, "hbm_bytes_per_launch": tot / max(launches, 1),
                      "hbm_bytes_per_step": tot / steps}
-conv = ["igemm", "wgrad"]
+conv = ["igemm", "pp", "wgrad"]
 summary["conv_mfma_family"] = {
     "launches_per_step": sum(summary[k]["launches_per_step"] for k in conv),
     "hbm_bytes_per_step": sum(summary[k]["hbm_bytes_per_step"] for k in conv),
