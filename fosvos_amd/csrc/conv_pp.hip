@@ -1,29 +1,46 @@
-// Forward 3x3 / pad 1 / stride 1 convolution (+ bias + ReLU [+ 2x2 ceil-mode max pool]) on bf16 NHWC: the PERSISTENT,
-// eight-wave "ping-pong" form of the implicit GEMM (src/networks/osvos_vgg.py:90-93 - Conv2d(3x3) + ReLU, and the MaxPool2d
-// that follows the last conv of a stage).
+// Forward 3x3 / pad 1 / stride 1 convolution (+ bias + ReLU [+ 2x2 ceil-mode max pool]) on bf16 NHWC: the PERSISTENT
+// eight-wave form of the implicit GEMM (src/networks/osvos_vgg.py:90-93 - Conv2d(3x3) + ReLU, and the MaxPool2d that follows
+// the last conv of a stage).
 //
 // Why a second kernel beside k_conv3x3_igemm (conv_igemm.hip): that kernel's workgroup lives 19 k clocks on a 64-channel
 // layer for 4.6 k clocks of matrix work (launch -> offsets -> first tile in LDS -> epilogue round trips), so two of them per
 // CU keep the matrix pipe 48 % busy (70 % at 256 channels).  Here ONE workgroup owns the CU for the whole launch:
 //   * 8 waves = two GROUPS of four (waves 0-3 / 4-7; wave w and w + 4 share a SIMD).  Each group owns a pixel tile
 //     (8 x 32 pixels x 64 output channels, 64 accumulator registers per lane) of its own.
-//   * time is cut into STEPS of one K chunk (32 input channels x 9 taps = 144 MFMAs per wave, ~2.3 k clocks): in step s
-//     group s & 1 runs the MFMAs of its chunk, the other group is in its MEMORY phase - it requests the operands of later
-//     chunks, and when its tile is finished it runs the epilogue (bias, ReLU, bf16, pool, global stores) straight from its
-//     accumulators.  One s_barrier per step.  The matrix pipe of every SIMD always has exactly one wave that wants it, and
-//     the wave beside it is doing memory work: the complementary pairing (matrix beside memory).
+//   * time is cut into SUPER-STEPS of one K chunk (32 input channels x 9 taps = 144 MFMAs per wave): both groups run the
+//     chunk's MFMAs on their own tiles in the same super-step (two waves per SIMD feed the matrix pipe), ONE bare s_barrier per
+//     super-step.  The memory work rides BETWEEN the taps: the requests for the next chunk (group 0 in front of tap 0,
+//     group 1 behind tap 4) and the stores of the tile finished in the previous super-step (group 1 behind taps 0-2, group 0
+//     behind taps 3-8), so that at any time at most one of the two waves of a SIMD is away from its MFMAs.
 //   * every operand byte goes global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write.
 //     Pixel tiles: [halo pixel][4 x 16 B] per chunk, the 16-byte k-group kq of pixel P at slot kq ^ ((P >> 1) & 2) - the
 //     swizzle sits on the SOURCE address, the LDS image is lane-linear - which makes every ds_read_b128 fragment read
-//     conflict-free for every tap shift (the read's 16-lane service groups mix two k-groups: lanes 0-3, 12-15, 20-27).
-//     Weights: the packed image's [tap][kq][64 channels][16 B] chunk, one copy shared by BOTH groups (group 1 runs one step
-//     behind group 0 on the same chunk index) and double-buffered; with <= 64 input channels the two chunks are loaded once
-//     and stay (weights stationary).
+//     conflict-free for every tap shift (the read's 16-lane service groups mix two k-groups: lanes 0-3, 12-15, 20-27;
+//     SQ_LDS_BANK_CONFLICT = 0 in profiles/r04_pmc_sq.txt).
+//     Weights: the packed image's [tap][kq][64 channels][16 B] chunk, one copy shared by BOTH groups, double-buffered; with
+//     <= 64 input channels the two chunks are loaded once and stay (weights stationary).
+//   * the epilogue runs straight from the accumulators: they START from the bias, are rounded to bf16 and clamped (ReLU on the
+//     packed pairs) into 32 registers when the tile's last chunk is done, and those are stored during the next super-step; the
+//     2 x 2 pool is a max over two fragments of the same lane and one DPP lane swap.
 //   * the workgroups are persistent: 256 of them (one per CU), each walks its share of the tiles; the ids that share an XCD
 //     take one contiguous eighth of the tile space, neighbouring tiles at the same time (shared halo rows meet in that L2).
 //   * channel order inside a 64-channel block is permuted in the LDS weight image so that a lane's accumulators hold 8
 //     CONSECUTIVE channels of a pixel: the epilogue stores 16 bytes per lane and instruction without an LDS round trip.
 // LDS: 2 x 36,864 (weights) + 2 groups x 2 x 21,760 (pixel tiles) + 256 (bias) = 161,024 of the CU's 163,840 bytes.
+//
+// Measured on the way (profiles/r04_lab_pp_*.txt; in-kernel stamps of lab builds, tools/pp_stamp_lab.py):
+//   * the first schedule ALTERNATED the groups ("ping-pong": in step s group s & 1 runs its MFMAs, the other one its memory
+//     phase, a barrier per step).  Its MFMA phase took 3.0-3.2 k clocks for 2.3 k of matrix work whatever the other group did
+//     (also with every memory operation switched off): ONE wave per SIMD issuing 16 MFMAs + 8 ds_read_b128 per tap reaches
+//     ~75 % of the pipe (tools/mfma_lds_lab.hip: 0.78); and a memory phase is bound by its wave's own in-order issue (one
+//     instruction per ~4 clocks: 600 scalar + 400 vector instructions = 4 k clocks until the tile walk, the descriptors and
+//     the DMA offsets of interior tiles were moved to a handful of scalar instructions), by ~170 clocks per LDS-DMA piece,
+//     and by ~300 clocks per 1-KB store.  conv3_2 at five frames: 148-152 us (igemm 140), conv1_2 156-178 (igemm 217).
+//   * this (lockstep) schedule: conv3_2 140, conv4_2 156 (alternating: 171), conv1_2 178; in the fine-tune step the two are
+//     equal (1253 vs 1252 frames/s; 1234 without the persistent kernel).  A super-step still takes ~7.0 k clocks for 4.6 k
+//     of matrix work: 10 DMA pieces per wave (1.7 k clocks during which its SIMD partner computes alone) and the stores.
+//   * LDS reads dealt out one (or two) per MFMA gap instead of in clumps behind four MFMAs: 4.2 k (3.5 k) clocks per phase
+//     instead of 3.1 k - a lone LDS instruction between two MFMAs costs far more than its share of a clump.
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -250,51 +267,108 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const unsigned bias_at = lds0 + LDS_BIAS + kq * 32;
 
     f32x4 acc[4][4];
-    int cp_c = 0;  // the chunk of the NEXT MFMA phase of this group
-    // The first tap's fragments of a group's next MFMA phase are read at the END of its memory phase, in front of the step
-    // barrier (its pixel chunk was published a step earlier; group 1's weight chunk too - group 0's is only published by that
-    // very barrier, so group 0 reads its first weight fragments behind it): the MFMA phase starts on operands in registers.
+    int cp_c = 0;  // the chunk of this super-step inside its tile
     bf16x8 af[4], wf[2][4];
 #define PP_RA(k_, tap_, i_)                                                                                   \
     af[i_] = __builtin_bit_cast(bf16x8, *(lds_u4_ptr)(size_t)(lds0 + LDS_A + (g * 2 + ((k_) & 1)) * A_BYTES +  \
                                                               a_sw[((i_) >> 1) + (tap_) / 3][(tap_) % 3] + ((i_) & 1) * 1024));
 #define PP_RW(k_, tap_, s_, j_) \
     wf[s_][j_] = __builtin_bit_cast(bf16x8, *(lds_u4_ptr)(size_t)(w_frag0 + ((k_) & 1) * W_BYTES + (tap_) * 4096 + (j_) * 256));
-    // a tile's first MFMAs take the bias as their C operand (block j of this lane: channels 32 (j >> 1) + 8 kq + 4 (j & 1) .. + 3):
-    // no accumulator initialisation pass
-    f32x4 bj[4];
-#define PP_RBIAS() \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) bj[j] =                                                      \
+    // a tile's accumulators start from the bias (block j of this lane: channels 32 (j >> 1) + 8 kq + 4 (j & 1) .. + 3), read
+    // from LDS straight into the accumulator registers
+#define PP_RBIAS()                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] =    \
         *(__attribute__((address_space(3))) const f32x4 *)(size_t)(bias_at + (j >> 1) * 128 + (j & 1) * 16);
-    auto preload = [&](int k) {  // k: the super-step of this group's next MFMA phase
-        if (k >= K || !cur.valid()) return;
-        if (cp_c == 0) { PP_RBIAS() }
-        PP_RA(k, 0, 0) PP_RA(k, 0, 1) PP_RA(k, 0, 2) PP_RA(k, 0, 3)
-        if (g == 1) { PP_RW(k, 0, 0, 0) PP_RW(k, 0, 0, 1) PP_RW(k, 0, 0, 2) PP_RW(k, 0, 0, 3) }
+
+    // ---- the finished tile's output: packed at the end of its last chunk, STORED during the next super-step, a few
+    // instructions at a time between the taps (a burst of twelve stores would hold this wave - and, the groups running in
+    // lockstep, its SIMD partner too - for thousands of clocks with no MFMA issued)
+    uint4 pk[4][2];
+    int dn_n = 0, dn_y0 = 0, dn_x0 = 0;  // the tile they belong to
+    int st_pending = 0;
+    auto pack_frag = [&](int i, int jp) {
+        unsigned u[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            const int e = 2 * e2;
+            u[e2] = pack2bf(acc[i][2 * jp + (e >> 2)][e & 3], acc[i][2 * jp + (e >> 2)][(e & 3) + 1]);
+            if constexpr (RELU) {
+                const fosvos_i16x2 zero = {0, 0};
+                u[e2] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(fosvos_i16x2, u[e2]), zero));
+            }
+        }
+        return make_uint4(u[0], u[1], u[2], u[3]);
+    };
+    auto pack_tile = [&]() {  // accumulators -> packed registers (+ the pooled vectors); the accumulators are free afterwards
+        if (!cur.valid() || PP_LAB(2)) return;
+        dn_n = cur.n; dn_y0 = cur.y0(); dn_x0 = cur.x0();
+        st_pending = 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pk[i][0] = pack_frag(i, 0);
+            pk[i][1] = pack_frag(i, 1);
+        }
+    };
+    // slot 0..3: fragment i's two 16-byte stores; slots 4, 5 (POOL): the pooled vectors of column half ih = slot - 4
+    auto store_slot = [&](int slot) {
+        if (!st_pending) return;
+        if (slot < 4) {
+            const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + (int64_t)dn_n * H * W * Cout, 0, H * W * Cout * 2, 0x00020000);
+            const int gy = dn_y0 + 2 * wm + (slot >> 1), gx = dn_x0 + (slot & 1) * 16 + cl;
+            const unsigned off = (gy < H && gx < W) ? (unsigned)(((gy * W + gx) * Cout + n0 + kq * 8) * 2) : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk[slot][0]), y_rsrc, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk[slot][1]), y_rsrc, off + 64, 0, 0);
+        } else if constexpr (POOL) {
+            // MaxPool2d(2, 2, ceil_mode=True) of the tile (its origin is even, so no window straddles two tiles): rows 2 wm and
+            // 2 wm + 1 are fragments ih and ih + 2 of the SAME lane, columns 2 c and 2 c + 1 are neighbouring lanes.  Post-ReLU
+            // values are >= 0: the maximum is an unsigned max on the packed pairs, and pixels outside the image count as zero
+            // (tiles on the right / bottom edge only), which makes the ragged last row / column windows come out right.
+            const int ih = slot - 4;
+            const int OH = (H + 1) >> 1, OW = (W + 1) >> 1;
+            const bool edge = dn_y0 + TH > H || dn_x0 + TW > W;  // wave-uniform
+            const auto p_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y_pool + (int64_t)dn_n * OH * OW * Cout, 0,
+                                                                  OH * OW * Cout * 2, 0x00020000);
+            const int oy = (dn_y0 >> 1) + wm, ox = (dn_x0 >> 1) + ih * 8 + (cl >> 1);
+            const bool ok = !(cl & 1) && oy < OH && ox < OW;
+            const unsigned off = ok ? (unsigned)(((oy * OW + ox) * Cout + n0 + kq * 8) * 2) : 0x80000000u;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                uint4 top = pk[ih][jp], bot = pk[ih + 2][jp];
+                if (edge) {
+                    const int gy = dn_y0 + 2 * wm, gx = dn_x0 + ih * 16 + cl;
+                    if (!(gy < H && gx < W)) top = make_uint4(0, 0, 0, 0);
+                    if (!(gy + 1 < H && gx < W)) bot = make_uint4(0, 0, 0, 0);
+                }
+                const uint4 m = max_nonneg_bf16x8(top, bot);
+                uint4 o;  // the neighbouring lane's column (quad_perm [1, 0, 3, 2])
+                o.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m.x, 0xB1, 0xF, 0xF, true);
+                o.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m.y, 0xB1, 0xF, 0xF, true);
+                o.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m.z, 0xB1, 0xF, 0xF, true);
+                o.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m.w, 0xB1, 0xF, 0xF, true);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, max_nonneg_bf16x8(m, o)), p_rsrc, off + jp * 64, 0, 0);
+            }
+        }
+    };
+    constexpr int N_SLOTS = POOL ? 6 : 4;
+
+    // the requests of super-step k + 1 (this group's pixel chunk; this wave's share of the weight chunk both groups use)
+    auto request_next = [&](int k) {
+        if (k + 1 < K && (NC > 2 || k + 1 < 2)) issue_w((k + 1) % NC, (k + 1) & 1, wave, 8);
+        ld_issue();
     };
 
-    // ---- prologue: weights of chunk 0 (all waves), this group's first chunk(s)
+    // ---- prologue: weights of chunk 0 (all waves), this group's first chunk
     issue_w(0, 0, wave, 8);
     ld_open_tile();
     ld_issue();
-    if (g == 0) ld_issue();  // group 0 keeps two chunks in flight (it computes first)
     wait_all();  // (the DMA pieces and the bias words this wave wrote to LDS)
     pp_barrier();
-    int first_phase = 1;  // group 0's first MFMA phase has no memory phase in front of it: it reads its first fragments itself
 
-    auto mfma_phase = [&](int k) {
-        if (cur.valid() && !PP_LAB(1)) {
-            // Software pipeline, pinned with sched_group_barrier (masks: 0x008 MFMA, 0x100 DS read, 0x002 VALU): the four
-            // MFMAs of pixel fragment i are followed by the read of the NEXT tap's fragment i (its register is dead by then)
-            // and, behind the first two rows, by the reads of the next tap's four weight fragments (second register set): every
-            // LDS read has at least eight MFMAs to land.  Left to itself hipcc reads one fragment, waits lgkmcnt(0), issues four
-            // MFMAs, and repeats.  Measured (stamps, 144 MFMAs per phase, one wave per SIMD): reads in clumps behind the rows
-            // 3.0-3.1 k clocks; ONE read in every MFMA gap 4.2 k (a lone LDS instruction between two MFMAs costs far more than
-            // its share of a clump); the floor of this instruction mix with one wave per SIMD is 0.78 of the MFMA rate
-            // (tools/mfma_lds_lab.hip), 2.95 k.
+    // Software pipeline of a tap, pinned with sched_group_barrier (masks: 0x008 MFMA, 0x100 DS read, 0x002 VALU): the four
+    // MFMAs of pixel fragment i, then the read of the NEXT tap's fragment i (its register is dead by then) and, behind the
+    // first two rows, the reads of the next tap's four weight fragments (second register set).
 #define PP_MM(tap_, i_, j_) \
     acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[(tap_) & 1][j_], af[i_], acc[i_][j_], 0, 0, 0);
-#define PP_MM0(i_, j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j_], af[i_], bj[j_], 0, 0, 0);
 #define PP_ROW_READS(n_, i_)                                                                                  \
     PP_RA(k, n_, i_)                                                                                          \
     if constexpr ((i_) < 2) {                                                                                 \
@@ -307,165 +381,60 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #define PP_ROW(tap_, i_)                                                                                      \
     PP_MM(tap_, i_, 0) PP_MM(tap_, i_, 1) PP_MM(tap_, i_, 2) PP_MM(tap_, i_, 3)                               \
     PP_ROW_READS((tap_) + 1, i_)
-#define PP_ROW0(i_)  /* tap 0 of a tile's first chunk: C = the bias vectors */                                \
-    PP_MM0(i_, 0) PP_MM0(i_, 1) PP_MM0(i_, 2) PP_MM0(i_, 3)                                                   \
-    PP_ROW_READS(1, i_)
 #define PP_TAP(tap_) { PP_ROW(tap_, 0) PP_ROW(tap_, 1) PP_ROW(tap_, 2) PP_ROW(tap_, 3) }
-#define PP_TAP0_BIAS() { PP_ROW0(0) PP_ROW0(1) PP_ROW0(2) PP_ROW0(3) }
 #define PP_TAP_LAST()                                                                                         \
     {                                                                                                         \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = \
             __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j], af[i], acc[i][j], 0, 0, 0);                      \
         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                                   \
     }
-            if (g == 0) {
-                if (first_phase) { PP_RBIAS() PP_RA(k, 0, 0) PP_RA(k, 0, 1) PP_RA(k, 0, 2) PP_RA(k, 0, 3) }
-                PP_RW(k, 0, 0, 0) PP_RW(k, 0, 0, 1) PP_RW(k, 0, 0, 2) PP_RW(k, 0, 0, 3)
-            }
-            first_phase = 0;
-            if (!PP_LAB(16)) __builtin_amdgcn_s_setprio(1);
-            if (cp_c == 0) PP_TAP0_BIAS()
-            else PP_TAP(0)
-            PP_TAP(1) PP_TAP(2) PP_TAP(3) PP_TAP(4) PP_TAP(5) PP_TAP(6) PP_TAP(7) PP_TAP_LAST()
-            __builtin_amdgcn_s_setprio(0);
-#undef PP_MM
-#undef PP_MM0
-#undef PP_ROW_READS
-#undef PP_ROW
-#undef PP_ROW0
-#undef PP_TAP
-#undef PP_TAP0_BIAS
-#undef PP_TAP_LAST
-        }
-        if (++cp_c == NC) cp_c = 0;
-    };
-
-    // The epilogue of the tile this group has just finished, straight from the accumulators, in TWO parts so that no memory
-    // phase is much longer than the MFMA phase beside it (what is slow are the stores: ~300 clocks of issue each):
-    //   part 1 (the memory phase right behind the tile's last chunk): bf16 rounding, ReLU -> packed registers (the
-    //           accumulators are free again), the stores of tile row 2 wm (fragments 0, 1) and the pooled map;
-    //   part 2 (this group's NEXT memory phase, two steps later): the stores of row 2 wm + 1 (fragments 2, 3: 16 registers
-    //           kept across one MFMA phase).
-    uint4 pk2[2][2];                     // fragments 2 and 3, packed, between the two parts
-    int dn_n = 0, dn_y0 = 0, dn_x0 = 0;  // the tile they belong to
-    int pk_pending = 0;
-    auto store_frag = [&](const __amdgpu_buffer_rsrc_t y_rsrc, int i, const uint4 &v0, const uint4 &v1) {
-        const int gy = dn_y0 + 2 * wm + (i >> 1), gx = dn_x0 + (i & 1) * 16 + cl;
-        const unsigned off = (gy < H && gx < W) ? (unsigned)(((gy * W + gx) * Cout + n0 + kq * 8) * 2) : 0x80000000u;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), y_rsrc, off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), y_rsrc, off + 64, 0, 0);
-    };
-    auto pack_frag = [&](int i, int jp) {
-        unsigned u[4];
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) {  // channels 8 q + 2 e2, + 1 of the 32-channel half jp
-            const int e = 2 * e2;
-            u[e2] = pack2bf(acc[i][2 * jp + (e >> 2)][e & 3], acc[i][2 * jp + (e >> 2)][(e & 3) + 1]);
-            // ReLU on the rounded pair: a bf16 is < 0 exactly when its bits, read as int16, are (and -0 -> +0)
-            if constexpr (RELU) {
-                const fosvos_i16x2 zero = {0, 0};
-                u[e2] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(fosvos_i16x2, u[e2]), zero));
-            }
-        }
-        return make_uint4(u[0], u[1], u[2], u[3]);
-    };
-    auto epilogue_part1 = [&]() {
-        if (!cur.valid() || PP_LAB(2)) return;
-        dn_n = cur.n; dn_y0 = cur.y0(); dn_x0 = cur.x0();
-        pk_pending = 1;
-        const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + (int64_t)dn_n * H * W * Cout, 0, H * W * Cout * 2, 0x00020000);
-        uint4 pk01[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            pk01[i][0] = pack_frag(i, 0);
-            pk01[i][1] = pack_frag(i, 1);
-            store_frag(y_rsrc, i, pk01[i][0], pk01[i][1]);
-            pk2[i][0] = pack_frag(i + 2, 0);
-            pk2[i][1] = pack_frag(i + 2, 1);
-        }
-        if constexpr (POOL) {
-            // MaxPool2d(2, 2, ceil_mode=True) of the tile (its origin is even, so no window straddles two tiles): rows 2 wm and
-            // 2 wm + 1 are fragments i and i + 2 of the SAME lane, columns 2 c and 2 c + 1 are neighbouring lanes.  Post-ReLU
-            // values are >= 0: the maximum is an unsigned max on the packed pairs, and pixels outside the image count as zero
-            // (tiles on the right / bottom edge only), which makes the ragged last row / column windows come out right.
-            const int OH = (H + 1) >> 1, OW = (W + 1) >> 1;
-            const bool edge = dn_y0 + TH > H || dn_x0 + TW > W;  // wave-uniform
-            const auto p_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y_pool + (int64_t)dn_n * OH * OW * Cout, 0,
-                                                                  OH * OW * Cout * 2, 0x00020000);
-            const int oy = (dn_y0 >> 1) + wm;
-#pragma unroll
-            for (int ih = 0; ih < 2; ++ih) {
-                const int ox = (dn_x0 >> 1) + ih * 8 + (cl >> 1);
-                const bool ok = !(cl & 1) && oy < OH && ox < OW;
-                const unsigned off = ok ? (unsigned)(((oy * OW + ox) * Cout + n0 + kq * 8) * 2) : 0x80000000u;
-#pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {
-                    uint4 top = pk01[ih][jp], bot = pk2[ih][jp];
-                    if (edge) {
-                        const int gy = dn_y0 + 2 * wm, gx = dn_x0 + ih * 16 + cl;
-                        if (!(gy < H && gx < W)) top = make_uint4(0, 0, 0, 0);
-                        if (!(gy + 1 < H && gx < W)) bot = make_uint4(0, 0, 0, 0);
-                    }
-                    const uint4 m = max_nonneg_bf16x8(top, bot);
-                    uint4 o;  // the neighbouring lane's column (quad_perm [1, 0, 3, 2])
-                    o.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m.x, 0xB1, 0xF, 0xF, true);
-                    o.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m.y, 0xB1, 0xF, 0xF, true);
-                    o.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m.z, 0xB1, 0xF, 0xF, true);
-                    o.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m.w, 0xB1, 0xF, 0xF, true);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, max_nonneg_bf16x8(m, o)), p_rsrc,
-                                                           off + jp * 64, 0, 0);
-                }
-            }
-        }
-    };
-    auto epilogue_part2 = [&]() {
-        if (!pk_pending) return;
-        pk_pending = 0;
-        const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + (int64_t)dn_n * H * W * Cout, 0, H * W * Cout * 2, 0x00020000);
-        store_frag(y_rsrc, 2, pk2[0][0], pk2[0][1]);
-        store_frag(y_rsrc, 3, pk2[1][0], pk2[1][1]);
-    };
-
-    // what a group does in the step after its MFMA phase on super-step k: request later operands, finish a tile
-    auto memory_phase = [&](int k_done) {  // k_done = -1: group 1's first memory phase (nothing computed yet)
-        if (g == 1 && k_done + 2 < K && (NC > 2 || k_done + 2 < 2))
-            issue_w((k_done + 2) % NC, (k_done + 2) & 1, wm, 4);  // the chunk both groups read in the NEXT super-step
-        ld_issue();
-        epilogue_part2();                // (of the tile finished one memory phase ago)
-        if (k_done >= 0 && cp_c == 0) {  // the phase before closed a tile
-            epilogue_part1();
-            cur.next();
-        }
-        preload(k_done + 1);
-    };
+// what rides between the taps of a super-step: group 0 requests the next chunks in FRONT of tap 0 and stores the finished tile
+// behind taps 3-8; group 1 stores behind taps 0-2 (two slots each) and requests behind tap 4 - at any time at most one of the
+// two waves of a SIMD is away from its MFMAs
+#define PP_BETWEEN(tap_)                                                                                      \
+    if (g == 0) {                                                                                             \
+        if constexpr ((tap_) >= 3 && (tap_) - 3 < N_SLOTS) store_slot((tap_) - 3);                            \
+    } else {                                                                                                  \
+        if constexpr ((tap_) < 3) {                                                                           \
+            store_slot(2 * (tap_));                                                                           \
+            if constexpr (2 * (tap_) + 1 < N_SLOTS) store_slot(2 * (tap_) + 1);                               \
+        }                                                                                                     \
+        if constexpr ((tap_) == 4) request_next(k);                                                           \
+    }
 
     for (int k = 0; k < K; ++k) {
-        // step 2 k: group 0 computes super-step k, group 1 is behind its super-step k - 1
         PP_STAMP(4 * k)
-        if (g == 0) {
-            mfma_phase(k);
-            PP_STAMP(256 + k)
-            wait_vm0();  // this group's pixel chunk requested in the step before: published by the barrier below
-        } else {
-            memory_phase(k - 1);
-        }
+        if (g == 0) request_next(k);
         PP_STAMP(4 * k + 1)
-        pp_barrier();
-        // step 2 k + 1
-        PP_STAMP(4 * k + 2)
-        if (g == 1) {
-            mfma_phase(k);
-            PP_STAMP(256 + k)
-            wait_vm0();  // the weights (and this group's pixels) requested in the step before: published by the barrier below
-        } else {
-            memory_phase(k);
+        if (cur.valid() && !PP_LAB(1)) {
+            if (cp_c == 0) { PP_RBIAS() }
+            PP_RA(k, 0, 0) PP_RA(k, 0, 1) PP_RA(k, 0, 2) PP_RA(k, 0, 3)
+            PP_RW(k, 0, 0, 0) PP_RW(k, 0, 0, 1) PP_RW(k, 0, 0, 2) PP_RW(k, 0, 0, 3)
+            PP_TAP(0) PP_BETWEEN(0) PP_TAP(1) PP_BETWEEN(1) PP_TAP(2) PP_BETWEEN(2) PP_TAP(3) PP_BETWEEN(3) PP_TAP(4) PP_BETWEEN(4)
+            PP_TAP(5) PP_BETWEEN(5) PP_TAP(6) PP_BETWEEN(6) PP_TAP(7) PP_BETWEEN(7) PP_TAP_LAST() PP_BETWEEN(8)
+        } else {  // a group without a tile in its last round: the memory work only
+            PP_BETWEEN(0) PP_BETWEEN(1) PP_BETWEEN(2) PP_BETWEEN(3) PP_BETWEEN(4) PP_BETWEEN(5) PP_BETWEEN(6) PP_BETWEEN(7) PP_BETWEEN(8)
         }
+        st_pending = 0;  // (every slot of the previous tile has been stored by now)
+        if (++cp_c == NC) {
+            cp_c = 0;
+            pack_tile();
+            cur.next();
+        }
+        PP_STAMP(4 * k + 2)
+        wait_vm0();  // this wave's requests of the super-step (and its stores): published by the barrier below
         PP_STAMP(4 * k + 3)
         pp_barrier();
     }
     PP_STAMP(4 * K)
-    if (g == 1) memory_phase(K - 1);
-    epilogue_part2();  // both groups: the second half of their last tile
+#pragma unroll
+    for (int slot = 0; slot < N_SLOTS; ++slot) store_slot(slot);  // the last tile
+#undef PP_MM
+#undef PP_ROW_READS
+#undef PP_ROW
+#undef PP_TAP
+#undef PP_TAP_LAST
+#undef PP_BETWEEN
 #undef PP_RA
 #undef PP_RW
 #undef PP_RBIAS

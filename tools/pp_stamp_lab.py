@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps of the persistent forward conv kernel (lab build only): per step, when a group's phase began, when its work
+"""Phase stamps of the persistent forward conv kernel (lab build only): per super-step, when it began, when the work
 was done (before the barrier), and when the barrier let it go.  usage: FOSVOS_HIP_LIB=.../libfosvos_hip_lab.so pp_stamp_lab.py [N H W Ci Co]"""
 import ctypes
 import os
@@ -38,21 +38,17 @@ def main():
         t0 = s[wg, 0, 0]
         nst = int((s[wg, 0, :256] > 0).sum())
         K = (nst - 1) // 4
-        print(f"workgroup {wg}: {K} super-steps, {nc} chunks per tile; clocks relative to the first stamp")
-        print("   k | step 2k: g0 mfma work | g1 mem work | step len || step 2k+1: g1 mfma work | g0 mem work | step len")
+        print(f"workgroup {wg}: {K} super-steps, {nc} chunks per tile (lockstep schedule); clocks")
+        print("   k | step length | g0: requests, taps+stores, dma wait | g1: taps+stores+requests, dma wait")
         rows = []
         for k in range(K):
-            a0, a1, a2, a3 = (int(v - t0) for v in s[wg, 0, 4 * k:4 * k + 4])
-            b0, b1, b2, b3 = (int(v - t0) for v in s[wg, 1, 4 * k:4 * k + 4])
-            nxt = int(s[wg, 0, 4 * k + 4] - t0)
-            w0 = int(s[wg, 0, 256 + k] - t0) - a0  # group 0's MFMA phase up to its wait for the DMA
-            w1 = int(s[wg, 1, 256 + k] - t0) - b2
-            rows.append((a1 - a0, b1 - b0, a2 - a0, b3 - b2, a3 - a2, nxt - a2, w0, w1))
-            if k < 12 or k >= K - 4:
-                print(f"{k:4d} | {a1 - a0:8d} | {b1 - b0:8d} | {a2 - a0:8d} || {b3 - b2:8d} | {a3 - a2:8d} | {nxt - a2:8d}"
-                      f"   (mfma before its DMA wait: g0 {w0}, g1 {w1})")
+            a = [int(v - t0) for v in s[wg, 0, 4 * k:4 * k + 5]]
+            b = [int(v - t0) for v in s[wg, 1, 4 * k:4 * k + 4]]
+            rows.append((a[4] - a[0], a[1] - a[0], a[2] - a[1], a[3] - a[2], b[2] - b[0], b[3] - b[2]))
+            if k < 12 or k >= K - 3:
+                print(f"{k:4d} | {a[4] - a[0]:8d} | {a[1] - a[0]:6d} {a[2] - a[1]:6d} {a[3] - a[2]:6d} | {b[2] - b[0]:6d} {b[3] - b[2]:6d}")
         r = np.array(rows[2:-2])
-        print("   mean (steady state):", " ".join(f"{v:9.0f}" for v in r.mean(axis=0)))
+        print("   mean (steady state):", " ".join(f"{v:8.0f}" for v in r.mean(axis=0)))
         print(f"   total {int(s[wg, 0, 4 * K] - t0)} clocks = {K} x {int(s[wg, 0, 4 * K] - t0) / max(K, 1):.0f}")
 
 
