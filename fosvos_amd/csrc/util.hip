@@ -22,6 +22,7 @@ namespace {
 struct ProfLaunch {
     const char *name;
     double flops;
+    hipStream_t stream;
 };
 std::mutex g_prof_mutex;
 std::vector<hipEvent_t> g_prof_events;   // 2 per launch slot
@@ -36,7 +37,7 @@ void prof_begin(const char *name, hipStream_t st, double flops) {
     t_prof_open = -1;
     const size_t slot = g_prof_launches.size();
     if (!g_prof_on || 2 * slot + 1 >= g_prof_events.size()) return;  // capacity reached: later launches go untimed
-    g_prof_launches.push_back({name, flops});
+    g_prof_launches.push_back({name, flops, st});
     if (hipEventRecord(g_prof_events[2 * slot], st) != hipSuccess) {
         g_prof_launches.pop_back();
         return;
@@ -83,9 +84,19 @@ extern "C" int fosvos_profile_stop(int device, fosvos_profile_record *out, int c
     int rc = FOSVOS_OK;
     if (hipDeviceSynchronize() != hipSuccess) rc = fail(FOSVOS_E_HIP, "profile_stop: hipDeviceSynchronize failed");
     int n = 0;
+    // lab builds: FOSVOS_PROF_TIMELINE=<file> also writes every launch's start (after the first launch's) and duration
+    FILE *timeline = nullptr;
+    if (const char *path = lab_env("FOSVOS_PROF_TIMELINE")) timeline = fopen(path, "w");
+    if (timeline) fprintf(timeline, "index,name,stream,start_us,dur_us\n");
     for (size_t i = 0; rc == FOSVOS_OK && i < g_prof_launches.size(); ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, g_prof_events[2 * i], g_prof_events[2 * i + 1]) != hipSuccess) continue;
+        if (timeline) {
+            float t0 = 0.f;
+            if (hipEventElapsedTime(&t0, g_prof_events[0], g_prof_events[2 * i]) == hipSuccess)
+                fprintf(timeline, "%zu,%s,%p,%.2f,%.2f\n", i, g_prof_launches[i].name, (void *)g_prof_launches[i].stream,
+                        t0 * 1e3, ms * 1e3);
+        }
         int k = 0;
         while (k < n && strncmp(out[k].name, g_prof_launches[i].name, sizeof(out[k].name) - 1) != 0) ++k;
         if (k == n) {
@@ -98,6 +109,7 @@ extern "C" int fosvos_profile_stop(int device, fosvos_profile_record *out, int c
         out[k].ms += ms;
         out[k].flops += g_prof_launches[i].flops;
     }
+    if (timeline) fclose(timeline);
     for (hipEvent_t e : g_prof_events) (void)hipEventDestroy(e);
     g_prof_events.clear();
     g_prof_launches.clear();

@@ -262,10 +262,11 @@ class GradSync:
         self._comm = None
         # Communication timing (COMM_TIMING / FOSVOS_COMM_TIMING=1; GPU only): per optimizer step, events on the
         # communication stream in front of and behind every bucket's all-reduce, an event on the main stream where the data-
-        # gradient chain of the cycle's last backward pass ended, and one where the optimizer step is ready to start: what
+        # gradient chain of the cycle's last backward pass ended, and one on the auxiliary stream where its weight-gradient
+        # kernels ended (the later of the two = when the optimizer step could start without communication): what
         # timing_summary() turns into per-bucket offsets and the exposed communication time per step.
         self.timing = COMM_TIMING or os.environ.get("FOSVOS_COMM_TIMING", "0") == "1"
-        self._steps: list = []   # per step: {"dgrad_end": ev, "ready": ev, "buckets": [(start ev, end ev, bytes)]}
+        self._steps: list = []   # per step: {"dgrad_end": ev, "aux_end": ev, "ready": ev, "buckets": [(start ev, end ev, bytes)]}
 
     def arm(self) -> None:
         if self.active and hasattr(self.net, "publish_grad_buckets"):
@@ -279,9 +280,9 @@ class GradSync:
             net.publish_grad_buckets = False
         # the bucket events exist only where the native backward pass recorded them (not under FOSVOS_PY_ENGINE=1)
         if self.flat.flat.is_cuda and hasattr(net, "wait_grad_bucket") and getattr(net, "publishes_grad_buckets", True):
-            if self._comm is None:
-                from fosvos_hip import engine  # one communication stream per device and process (engine.shared_stream)
-                d = self.flat.flat.device
+            from fosvos_hip import engine
+            d = self.flat.flat.device
+            if self._comm is None:  # one communication stream per device and process (engine.shared_stream)
                 self._comm = engine.shared_stream(d.index if d.index is not None else torch.cuda.current_device(), "comm")
             main = torch.cuda.current_stream(self.flat.flat.device)
             comm = self._comm
@@ -293,8 +294,12 @@ class GradSync:
 
             on_bucket = None
             if self.timing:
-                rec = {"dgrad_end": torch.cuda.Event(enable_timing=True), "ready": None, "buckets": []}
+                rec = {"dgrad_end": torch.cuda.Event(enable_timing=True), "aux_end": torch.cuda.Event(enable_timing=True),
+                       "ready": None, "buckets": []}
                 rec["dgrad_end"].record(main)  # (the backward call has returned: its data-gradient chain ends here on `main`)
+                # ... and its weight-gradient kernels end here on the auxiliary stream: without communication the optimizer
+                # step could start at the later of the two
+                rec["aux_end"].record(engine.shared_stream(d.index if d.index is not None else torch.cuda.current_device(), "aux"))
                 self._steps.append(rec)
                 slices = self.flat.slices
 
@@ -336,22 +341,25 @@ class GradSync:
 
     def timing_summary(self) -> Optional[dict]:
         """After a device sync: per bucket the mean start / end of its all-reduce in ms after the end of the data-gradient
-        chain, its bytes, and `comm_exposed_ms_per_step` = how long after the optimizer step was ready the last bucket
-        ended (0 when the communication hid behind the rest of the backward pass)."""
+        chain, its bytes, `compute_done_ms_after_dgrad_end` (when the weight-gradient stream ended: the moment the optimizer
+        step could have started without communication) and `comm_exposed_ms_per_step` = how long after THAT the last
+        bucket's all-reduce ended (0 when the communication hid behind the rest of the backward pass)."""
         steps = [r for r in self._steps if r["ready"] is not None and r["buckets"] and all(b[1] is not None for b in r["buckets"])]
         if not steps:
             return None
         n_b = len(steps[0]["buckets"])
         start = [0.0] * n_b
         end = [0.0] * n_b
-        exposed = 0.0
+        exposed, done = 0.0, 0.0
         for r in steps:
             for i, (e0, e1, _) in enumerate(r["buckets"]):
                 start[i] += r["dgrad_end"].elapsed_time(e0)
                 end[i] += r["dgrad_end"].elapsed_time(e1)
-            exposed += max(0.0, r["ready"].elapsed_time(r["buckets"][-1][1]))
+            compute_done = max(0.0, r["dgrad_end"].elapsed_time(r["aux_end"]))
+            done += compute_done
+            exposed += max(0.0, r["dgrad_end"].elapsed_time(r["buckets"][-1][1]) - compute_done)
         n = len(steps)
-        return {"optimizer_steps": n, "comm_exposed_ms_per_step": exposed / n,
+        return {"optimizer_steps": n, "comm_exposed_ms_per_step": exposed / n, "compute_done_ms_after_dgrad_end": done / n,
                 "buckets": [{"bytes": steps[0]["buckets"][i][2], "start_ms_after_dgrad_end": start[i] / n,
                              "end_ms_after_dgrad_end": end[i] / n} for i in range(n_b)],
                 "note": "events on the communication stream around every bucket's all-reduce, relative to the end of the "
