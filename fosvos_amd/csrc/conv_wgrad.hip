@@ -409,19 +409,37 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradReduceTable t) 
         }
         *d = acc;
     }
-    if (local == 0 && q.db) {  // the layer's bias gradient: S partials per channel, fixed order
-        // 16 partials in flight per thread (a rolled loop paid one L2 round trip per split: 65 us at 250 splits)
-        for (int co = threadIdx.x; co < q.Co; co += 256) {
+    if (local == 0 && q.db) {  // the layer's bias gradient: S_bias partials per channel, fixed order
+        // The 256 threads are P parts x Cg channels (Cg = Co rounded up to a power of two, at most 256): part p adds its
+        // contiguous range of the partials with 16 loads in flight (a rolled loop paid one L2 round trip per partial: 65 us at
+        // 250 splits; one thread per channel still left 16 of 256 threads walking 750 partials for a side_prep layer), then
+        // the parts are added in order.
+        __shared__ float s_part[256];
+        int Cg = 1;
+        while (Cg < q.Co && Cg < 256) Cg <<= 1;
+        const int P = 256 / Cg, part = threadIdx.x / Cg, cl = threadIdx.x - part * Cg;
+        const int per = (q.S_bias + P - 1) / P, s_lo = part * per, s_hi = min(s_lo + per, q.S_bias);
+        for (int co0 = 0; co0 < q.Co; co0 += Cg) {
+            const int co = co0 + cl;
             float acc_b = 0.f;
-            for (int s0 = 0; s0 < q.S_bias; s0 += 16) {
-                float v[16];
+            if (co < q.Co) {
+                for (int s0 = s_lo; s0 < s_hi; s0 += 16) {
+                    float v[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = q.bias_part[(int64_t)min(s0 + j, q.S_bias - 1) * q.Cor + co];
+                    for (int j = 0; j < 16; ++j) v[j] = q.bias_part[(int64_t)min(s0 + j, s_hi - 1) * q.Cor + co];
 #pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if (s0 + j < q.S_bias) acc_b += v[j];
+                    for (int j = 0; j < 16; ++j)
+                        if (s0 + j < s_hi) acc_b += v[j];
+                }
             }
-            q.db[co] = q.accumulate ? q.db[co] + acc_b : acc_b;
+            if (co0) __syncthreads();  // (the previous round's parts have been read)
+            s_part[threadIdx.x] = acc_b;
+            __syncthreads();
+            if (part == 0 && co < q.Co) {
+                float t = s_part[cl];
+                for (int pp = 1; pp < P; ++pp) t += s_part[pp * Cg + cl];
+                q.db[co] = q.accumulate ? q.db[co] + t : t;
+            }
         }
     }
 }

@@ -173,13 +173,17 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadPtrs p, HeadGeom g, const 
 //   T_c = sum_window filt[ky][kx][c] * d_fused[Y,X]      G = sum_window filt1[ky][kx] * d_side_out[Y,X]
 //   d_side[c]  = fuse_w[16s+c] * T_c + dsn_w[s][c] * G
 //   d_fuse_w[16s+c] += side[c] * T_c;  d_dsn_w[s][c] += side[c] * G;  d_dsn_b[s] += G
-// from LDS only (filter reads: 16 consecutive floats per pixel group; window reads: broadcasts).
+// from LDS only.  The tap sums are taken by thread (tap slice ts, pixel pl, channel quad cq): one 16-byte filter read serves
+// four channels and (scales 1-3) one 16-byte window read four taps - 16 multiply-adds per five LDS instructions, where one
+// thread per (pixel, channel) walking all k x k taps paid two LDS reads per multiply-add and was bound by LDS issue at every
+// scale (52 / 25 / 18 / 27 us for five 480x854 frames, on the critical path between the passes).  The large filters are cut
+// into TS tap slices (row ranges) whose partial sums meet in LDS in a fixed order.
 // Block partials go to the workspace as slabs [block][3][16]; k_head_finish sums them in order.
 template <int S> struct HeadTile;
-template <> struct HeadTile<0> { static constexpr int TI = 8, TJ = 32; };
-template <> struct HeadTile<1> { static constexpr int TI = 4, TJ = 16; };
-template <> struct HeadTile<2> { static constexpr int TI = 4, TJ = 4; };
-template <> struct HeadTile<3> { static constexpr int TI = 2, TJ = 8; };
+template <> struct HeadTile<0> { static constexpr int TI = 8, TJ = 32, TS = 1; };
+template <> struct HeadTile<1> { static constexpr int TI = 4, TJ = 16, TS = 1; };
+template <> struct HeadTile<2> { static constexpr int TI = 4, TJ = 4, TS = 4; };
+template <> struct HeadTile<3> { static constexpr int TI = 2, TJ = 8, TS = 4; };
 
 template <int S, bool WITH_SIDE_OUT>
 __global__ __launch_bounds__(256) void k_head_bwd_scale(const float *__restrict__ side, const float *__restrict__ filt,
@@ -239,24 +243,71 @@ __global__ __launch_bounds__(256) void k_head_bwd_scale(const float *__restrict_
     if (WITH_SIDE_OUT)
         for (int e = tid; e < k * k; e += 256) sF1[e] = filt1[e];
     __syncthreads();
+    // ---- the tile's pixels in chunks of PXC = 64 / TS.  Phase 1: partial tap sums, thread (ts, pl, cq): pixel pl of the
+    // chunk, channels 4 cq .. 4 cq + 3, filter rows ts k / TS .. (ts + 1) k / TS - 1
+    constexpr int TS = HeadTile<S>::TS, NPX = TI * TJ, PXC = 64 / TS;
+    static_assert(NPX % PXC == 0 && PXC % 16 == 0, "whole chunks; phase 2 walks a chunk 16 pixels at a time");
+    __shared__ __attribute__((aligned(16))) float sP[TS][PXC][16];
+    __shared__ float sG[TS][PXC];
     const int c = tid & 15, pl = tid >> 4;
     const float fw = fuse_w16[c];
     const float dw = WITH_SIDE_OUT ? dsn_w16[c] : 0.f;
     float a = 0.f, b = 0.f, g = 0.f;
-    for (int p = pl; p < TI * TJ; p += 16) {
+#pragma unroll 1
+    for (int p0 = 0; p0 < NPX; p0 += PXC) {
+    if (p0) __syncthreads();  // the previous chunk's partial sums have been read
+    {
+        const int cq = tid & 3, pl1 = (tid >> 2) % PXC, ts = tid / (4 * PXC);
+        const int il = (p0 + pl1) / TJ, jl = (p0 + pl1) - il * TJ;
+        const float *wp = sW + il * f * WC + jl * f;
+        const float *wp1 = sW1 + il * f * WC + jl * f;
+        const float4 *sF4 = reinterpret_cast<const float4 *>(sF);
+        float4 T4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float G1 = 0.f;
+        constexpr int KY = k / TS;
+#pragma unroll 2
+        for (int ky = ts * KY; ky < (ts + 1) * KY; ++ky) {
+            if constexpr (S >= 1) {  // the window row of a pixel starts on a 16-byte boundary: four taps per read
+#pragma unroll
+                for (int kx = 0; kx < k; kx += 4) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wp + ky * WC + kx);
+                    const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float4 f4 = sF4[(ky * k + kx + e) * 4 + cq];
+                        T4.x += f4.x * wv[e]; T4.y += f4.y * wv[e]; T4.z += f4.z * wv[e]; T4.w += f4.w * wv[e];
+                    }
+                    if (WITH_SIDE_OUT && cq == 0) {
+                        const float4 v4 = *reinterpret_cast<const float4 *>(wp1 + ky * WC + kx);
+                        G1 += sF1[ky * k + kx] * v4.x + sF1[ky * k + kx + 1] * v4.y + sF1[ky * k + kx + 2] * v4.z +
+                              sF1[ky * k + kx + 3] * v4.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int kx = 0; kx < k; ++kx) {
+                    const float wv = wp[ky * WC + kx];
+                    const float4 f4 = sF4[(ky * k + kx) * 4 + cq];
+                    T4.x += f4.x * wv; T4.y += f4.y * wv; T4.z += f4.z * wv; T4.w += f4.w * wv;
+                    if (WITH_SIDE_OUT && cq == 0) G1 += sF1[ky * k + kx] * wp1[ky * WC + kx];
+                }
+            }
+        }
+        *reinterpret_cast<float4 *>(&sP[ts][pl1][4 * cq]) = T4;
+        if (WITH_SIDE_OUT && cq == 0) sG[ts][pl1] = G1;
+    }
+    __syncthreads();
+    // ---- phase 2: thread (pixel pl + 16 m of the chunk, channel c) adds the slices in order and finishes its element
+    for (int pc = pl; pc < PXC; pc += 16) {
+        const int p = p0 + pc;
         const int il = p / TJ, jl = p - il * TJ;
         const int i = i0 + il, j = j0 + jl;
         if (i >= hs || j >= ws) continue;
-        float T = 0.f, G = 0.f;
-        const float *wp = sW + il * f * WC + jl * f;
-        const float *wp1 = sW1 + il * f * WC + jl * f;
-#pragma unroll 4
-        for (int ky = 0; ky < k; ++ky) {
-#pragma unroll 8
-            for (int kx = 0; kx < k; ++kx) {
-                T += sF[(ky * k + kx) * 16 + c] * wp[ky * WC + kx];
-                if (WITH_SIDE_OUT) G += sF1[ky * k + kx] * wp1[ky * WC + kx];
-            }
+        float T = sP[0][pc][c], G = WITH_SIDE_OUT ? sG[0][pc] : 0.f;
+#pragma unroll
+        for (int ts = 1; ts < TS; ++ts) {
+            T += sP[ts][pc][c];
+            if (WITH_SIDE_OUT) G += sG[ts][pc];
         }
         const int64_t pix = ((int64_t)n * hs + i) * ws + j;
         const float sv = side[pix * 16 + c];
@@ -269,6 +320,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_scale(const float *__restrict_
             if (c == 0) g += G;
         }
     }
+    }  // chunks
     // block reduction over lanes with equal c: xor 16, 32 inside the wave, then LDS across waves
     a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
     b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);

@@ -167,10 +167,14 @@ __global__ __launch_bounds__(64) void k_finish(int64_t n, int size_average, cons
 extern "C" size_t fosvos_cbce_workspace_bytes(int64_t) { return sizeof(Ws); }
 
 namespace {
+// parts: which of the three launches run (FOSVOS_CBCE_COUNT | _LOSS | _FINISH; the one-call entry points pass all three)
 int cbce_impl(const float *logits, const float *label, int64_t numel, int n_frames, int size_average, float grad_scale,
               const double *batch_counts, float *loss_out, float *grad, void *workspace, size_t workspace_bytes,
-              int device, void *stream) {
-    FOSVOS_REQUIRE(logits && label && loss_out && workspace, FOSVOS_E_ARG, "cbce_loss: null pointer");
+              int device, void *stream, int parts = FOSVOS_CBCE_COUNT | FOSVOS_CBCE_LOSS | FOSVOS_CBCE_FINISH) {
+    FOSVOS_REQUIRE(parts > 0 && parts <= 7, FOSVOS_E_ARG, "cbce_loss: parts=%d", parts);
+    FOSVOS_REQUIRE(workspace && (label || !(parts & (FOSVOS_CBCE_COUNT | FOSVOS_CBCE_LOSS))) &&
+                       (logits || !(parts & FOSVOS_CBCE_LOSS)) && (loss_out || !(parts & FOSVOS_CBCE_FINISH)),
+                   FOSVOS_E_ARG, "cbce_loss: null pointer");
     FOSVOS_REQUIRE(numel > 0, FOSVOS_E_SHAPE, "cbce_loss: numel=%lld", (long long)numel);
     FOSVOS_REQUIRE(n_frames >= 1 && n_frames <= 65535, FOSVOS_E_SHAPE, "cbce_loss: n_frames=%d", n_frames);
     FOSVOS_REQUIRE(n_frames == 1 || numel % 4 == 0, FOSVOS_E_SHAPE,
@@ -178,25 +182,30 @@ int cbce_impl(const float *logits, const float *label, int64_t numel, int n_fram
                    (long long)numel);
     FOSVOS_REQUIRE(workspace_bytes >= n_frames * sizeof(Ws), FOSVOS_E_WORKSPACE, "cbce_loss: workspace %zu < %zu",
                    workspace_bytes, n_frames * sizeof(Ws));
-    FOSVOS_REQUIRE(((uintptr_t)logits % 16 == 0) && ((uintptr_t)label % 16 == 0) && (!grad || (uintptr_t)grad % 16 == 0),
+    FOSVOS_REQUIRE((!logits || (uintptr_t)logits % 16 == 0) && (!label || (uintptr_t)label % 16 == 0) &&
+                       (!grad || (uintptr_t)grad % 16 == 0),
                    FOSVOS_E_ARG, "cbce_loss: pointers must be 16-byte aligned");
     FOSVOS_ENTER(device);
     int blocks = (int)cdiv(numel, (int64_t)kBlock * kPerThread);
     if (blocks > kMaxBlocks) blocks = kMaxBlocks;
     Ws *ws = reinterpret_cast<Ws *>(workspace);
     hipStream_t s = (hipStream_t)stream;
-    if (!batch_counts) {
+    if (!batch_counts && (parts & FOSVOS_CBCE_COUNT)) {
         FOSVOS_PROF("k_count", s, 0.0);
         hipLaunchKernelGGL(k_count, dim3(blocks, n_frames), dim3(kBlock), 0, s, label, numel, ws);
         FOSVOS_LAUNCH_CHECK();
     }
-    FOSVOS_PROF("k_loss", s, 0.0);
-    hipLaunchKernelGGL(k_loss, dim3(blocks, n_frames), dim3(kBlock), 0, s, logits, label, numel, size_average, grad_scale, grad,
-                       ws, blocks, batch_counts);
-    FOSVOS_LAUNCH_CHECK();
-    FOSVOS_PROF("k_finish", s, 0.0);
-    hipLaunchKernelGGL(k_finish, dim3(n_frames), dim3(64), 0, s, numel, size_average, ws, blocks, loss_out, batch_counts);
-    FOSVOS_LAUNCH_CHECK();
+    if (parts & FOSVOS_CBCE_LOSS) {
+        FOSVOS_PROF("k_loss", s, 0.0);
+        hipLaunchKernelGGL(k_loss, dim3(blocks, n_frames), dim3(kBlock), 0, s, logits, label, numel, size_average, grad_scale,
+                           grad, ws, blocks, batch_counts);
+        FOSVOS_LAUNCH_CHECK();
+    }
+    if (parts & FOSVOS_CBCE_FINISH) {
+        FOSVOS_PROF("k_finish", s, 0.0);
+        hipLaunchKernelGGL(k_finish, dim3(n_frames), dim3(64), 0, s, numel, size_average, ws, blocks, loss_out, batch_counts);
+        FOSVOS_LAUNCH_CHECK();
+    }
     return FOSVOS_OK;
 }
 }  // namespace
@@ -213,6 +222,13 @@ extern "C" int fosvos_cbce_loss_frames(const float *logits, const float *label, 
                                        size_t workspace_bytes, int device, void *stream) {
     return cbce_impl(logits, label, frame_numel, n_frames, size_average, grad_scale, nullptr, loss_out, grad, workspace,
                      workspace_bytes, device, stream);
+}
+
+extern "C" int fosvos_cbce_loss_frames_parts(const float *logits, const float *label, int64_t frame_numel, int n_frames,
+                                             int size_average, float grad_scale, float *loss_out, float *grad,
+                                             void *workspace, size_t workspace_bytes, int parts, int device, void *stream) {
+    return cbce_impl(logits, label, frame_numel, n_frames, size_average, grad_scale, nullptr, loss_out, grad, workspace,
+                     workspace_bytes, device, stream, parts);
 }
 
 extern "C" int fosvos_cbce_loss_batch_counts(const float *logits, const float *label, int64_t numel, int size_average,

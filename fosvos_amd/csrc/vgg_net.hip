@@ -354,6 +354,9 @@ extern "C" int fosvos_vgg_backward(fosvos_ctx *ctx, const fosvos_vgg_weights *w,
         if (par) FOSVOS_HIP_CHECK(hipEventRecord(ev[16 + i], sa));
     }
     FOSVOS_TRY(publish(13));  // d_side[3] and its slabs are complete: the finish pass and side_prep[3]'s wgrad may run
+    // (the finish pass - five blocks, 50-130 us - stays here, at the head of the weight-gradient stream, where the small
+    // kernels between the passes cover it: moved to the end of the main stream it delays the next cycle's first kernel,
+    // -2.3 % on the step, profiles/r04_lab_step_ab_head_loss.txt)
     FOSVOS_TRY(head_bwd_finish(ha, sa));
 
     // ---- stages 4..0

@@ -17,7 +17,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
 LIB_PATH = os.environ.get("FOSVOS_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 CONV_RELU = 1
 CONV_OUT_F32 = 2
 
@@ -138,6 +138,8 @@ SIGNATURES = {
     "fosvos_cbce_workspace_bytes": (c_size_t, [c_int64]),
     "fosvos_cbce_loss_frames": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                         c_size_t, c_int, c_void_p]),
+    "fosvos_cbce_loss_frames_parts": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p,
+                                              c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "fosvos_cbce_loss_batch_counts": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_size_t, c_int, c_void_p]),
     "fosvos_sgd_momentum_step": (c_int, [c_void_p, c_int, c_int64, c_float, c_int, c_int, c_void_p]),

@@ -533,6 +533,70 @@ def cbce_loss_frames(logits: torch.Tensor, label: torch.Tensor, size_average: bo
     return losses, grad
 
 
+CBCE_COUNT, CBCE_LOSS, CBCE_FINISH = 1, 2, 4
+
+
+class CbceFramesStaged(object):
+    """``cbce_loss_frames`` in its three launches (fosvos_cbce_loss_frames_parts), for a loop that has a forward pass to
+    put behind the first and a backward pass behind the second: the class counts need only the labels, the backward pass
+    only the gradient - counting beside the forward pass and writing the loss VALUES behind the backward pass takes two
+    small dependent launches (and the copy of the values to the host) off the path between the two passes.
+
+        staged = CbceFramesStaged(label)              # counts; before the forward pass
+        losses, grad = staged.loss(logits, ...)       # `losses` is allocated, NOT yet written
+        ...backward pass...
+        staged.finish()                               # now `losses` holds the values (stream order)
+
+    Same stream for all three calls.  Frames whose element count is not a multiple of 4 are not supported here (the caller
+    falls back to cbce_loss_frames)."""
+
+    def __init__(self, label: torch.Tensor):
+        _need(label, _F32, "CbceFramesStaged label")
+        if label.dim() < 2:
+            raise ValueError(f"CbceFramesStaged: label {tuple(label.shape)}")
+        self.n = label.shape[0]
+        self.per = label.numel() // self.n
+        if self.per % 4 or label.data_ptr() % 16:
+            raise ValueError("CbceFramesStaged: frames must be a multiple of 4 elements and 16-byte aligned")
+        L = lib()
+        self.label = label
+        # the stages share this workspace across the passes in between: its own tensor, not the ops' scratch
+        self.wsn = self.n * L.fosvos_cbce_workspace_bytes(self.per)
+        self.ws = torch.empty((self.wsn,), dtype=torch.uint8, device=label.device)
+        self.losses = None
+        self.size_average = None
+        dev, st = _ctx(label)
+        t0 = _pb()
+        check(L.fosvos_cbce_loss_frames_parts(None, label.data_ptr(), self.per, self.n, 0, 1.0, None, None, self.ws.data_ptr(),
+                                              self.wsn, CBCE_COUNT, dev, st), "cbce_loss_frames_parts(count)")
+        _pe(t0, "cbce_loss", 0.0, label.numel() * 4)
+
+    def loss(self, logits: torch.Tensor, size_average: bool = True, want_grad: bool = True, grad_scale: float = 1.0):
+        _need(logits, _F32, "CbceFramesStaged logits")
+        if logits.shape != self.label.shape or logits.data_ptr() % 16:
+            raise ValueError(f"CbceFramesStaged: logits {tuple(logits.shape)} vs label {tuple(self.label.shape)}")
+        self.losses = torch.empty((self.n,), dtype=_F32, device=logits.device)
+        self.size_average = bool(size_average)
+        grad = torch.empty_like(logits) if want_grad else None
+        dev, st = _ctx(logits)
+        t0 = _pb()
+        check(lib().fosvos_cbce_loss_frames_parts(logits.data_ptr(), self.label.data_ptr(), self.per, self.n,
+                                                  1 if size_average else 0, float(grad_scale), None, _p(grad),
+                                                  self.ws.data_ptr(), self.wsn, CBCE_LOSS, dev, st),
+              "cbce_loss_frames_parts(loss)")
+        _pe(t0, "cbce_loss", 0.0, logits.numel() * (12 if want_grad else 8))
+        return self.losses, grad
+
+    def finish(self) -> torch.Tensor:
+        if self.losses is None:
+            raise RuntimeError("CbceFramesStaged.finish before loss")
+        dev, st = _ctx(self.losses)
+        check(lib().fosvos_cbce_loss_frames_parts(None, None, self.per, self.n, 1 if self.size_average else 0, 1.0,
+                                                  self.losses.data_ptr(), None, self.ws.data_ptr(), self.wsn, CBCE_FINISH,
+                                                  dev, st), "cbce_loss_frames_parts(finish)")
+        return self.losses
+
+
 # ------------------------------------------------------------------------------------------ thin-channel ResNet path
 def fold_conv_bn(w: torch.Tensor, conv_bias: Optional[torch.Tensor] = None, bn: Optional[Sequence] = None):
     """(w * s, bn_bias - mean * s [+ conv_bias * s]) with s = bn_weight / sqrt(var + eps): fp32 OIHW in and out."""

@@ -102,22 +102,38 @@ class _CBCELossFrames(torch.autograd.Function):
     gradients in one buffer so that backward is a single scale."""
 
     @staticmethod
-    def forward(ctx, output, label, size_average, backward_seed=None):
+    def forward(ctx, output, label, size_average, backward_seed=None, staged=None):
         ctx.seed_ptr, ctx.seed_value = _seed_of(backward_seed)
-        losses, grad = ops.cbce_loss_frames(output.contiguous().float(), label.contiguous().float(),
-                                            size_average=bool(size_average), want_grad=output.requires_grad,
-                                            grad_scale=ctx.seed_value)
+        if staged is not None:  # the class counts are already in the staged loss's workspace; the values come with finish()
+            losses, grad = staged.loss(output.contiguous().float(), size_average=bool(size_average),
+                                       want_grad=output.requires_grad, grad_scale=ctx.seed_value)
+        else:
+            losses, grad = ops.cbce_loss_frames(output.contiguous().float(), label.contiguous().float(),
+                                                size_average=bool(size_average), want_grad=output.requires_grad,
+                                                grad_scale=ctx.seed_value)
         ctx.grad = grad
         return losses
 
     @staticmethod
     def backward(ctx, g):
         if ctx.grad is None:
-            return None, None, None, None
-        return _scaled(ctx, g), None, None, None
+            return None, None, None, None, None
+        return _scaled(ctx, g), None, None, None, None
 
 
-def class_balanced_cross_entropy_loss_frames(output, label, size_average=True, backward_seed=None):
+def stage_frames_loss(label):
+    """Start a per-frame loss whose three launches the caller spreads around its forward / backward pass
+    (ops.CbceFramesStaged): counts the classes of ``label`` now.  None when the frames do not qualify (the one-call path
+    then does everything).  Pass the result as ``staged=`` to class_balanced_cross_entropy_loss_frames - whose values are
+    then written only by ``staged.finish()`` - and call that behind the backward pass."""
+    if not label.is_cuda or label.dtype != torch.float32 or not label.is_contiguous() or label.dim() < 2:
+        return None
+    if (label.numel() // label.shape[0]) % 4 or label.data_ptr() % 16:
+        return None
+    return ops.CbceFramesStaged(label)
+
+
+def class_balanced_cross_entropy_loss_frames(output, label, size_average=True, backward_seed=None, staged=None):
     """``class_balanced_cross_entropy_loss`` of each frame of a batch separately: a [N] tensor whose element i equals
     ``class_balanced_cross_entropy_loss(output[i:i+1], label[i:i+1], size_average)``.  Not in the reference; the
     online loop uses it when it runs several micro-batches of an accumulation cycle as one batched pass, where every
@@ -130,7 +146,9 @@ def class_balanced_cross_entropy_loss_frames(output, label, size_average=True, b
     if tuple(label.shape) != tuple(output.shape):
         raise ValueError("class_balanced_cross_entropy_loss_frames: output {} vs label {}".format(
             tuple(output.shape), tuple(label.shape)))
-    return _CBCELossFrames.apply(output, label, size_average, backward_seed)
+    if staged is not None and (staged.label.data_ptr() != label.data_ptr() or tuple(staged.label.shape) != tuple(label.shape)):
+        raise ValueError("class_balanced_cross_entropy_loss_frames: `staged` was started on another label tensor")
+    return _CBCELossFrames.apply(output, label, size_average, backward_seed, staged)
 
 
 def crop_offsets(size, target):

@@ -20,7 +20,7 @@ import torch
 from torch import optim
 
 from config.mypath import Path as P
-from layers.osvos_layers import class_balanced_cross_entropy_loss, class_balanced_cross_entropy_loss_frames
+from layers.osvos_layers import class_balanced_cross_entropy_loss, class_balanced_cross_entropy_loss_frames, stage_frames_loss
 from util import gpu_handler, io_helper, experiment_helper, args_helper
 from util.logger import get_logger
 from util.network_provider import NetworkProvider, provider_mapping
@@ -93,10 +93,13 @@ def _group_window() -> int:
         return 16
 
 
-def _losses_per_frame(fused, gts, backward_seed=None):
-    """[k] per-frame losses of a batched pass; one fused op on the GPU, the reference's function per slice elsewhere."""
+def _losses_per_frame(fused, gts, backward_seed=None, staged=None):
+    """[k] per-frame losses of a batched pass; one fused op on the GPU, the reference's function per slice elsewhere.
+    staged: the loss was started beside the forward pass (osvos_layers.stage_frames_loss): its values are written by
+    staged.finish(), which the caller queues behind the backward pass."""
     if fused.is_cuda and class_balanced_cross_entropy_loss is _hip_cbce:
-        return class_balanced_cross_entropy_loss_frames(fused, gts, size_average=False, backward_seed=backward_seed)
+        return class_balanced_cross_entropy_loss_frames(fused, gts, size_average=False, backward_seed=backward_seed,
+                                                        staged=staged)
     return torch.stack([class_balanced_cross_entropy_loss(fused[i:i + 1], gts[i:i + 1], size_average=False)
                         for i in range(fused.shape[0])])
 
@@ -144,6 +147,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
 
     # lab switch (A/B only): 0 = separate gradient memsets behind the optimizer step and an unannounced backward seed
     fuse_small = os.environ.get('FOSVOS_LOOP_FUSE', '1') != '0'
+    stage_losses = os.environ.get('FOSVOS_STAGE_LOSS', '1') != '0'  # (0: the loss of a batched pass in one call, as before)
     # A cycle whose micro-batches cannot run as ONE batched pass (frames of different sizes - the reference's augmentation
     # draws a new scale per iteration - or FOSVOS_MICROBATCH_GROUP < nAveGrad) runs its passes on two alternating streams:
     # the weights do not change inside a cycle and every pass has its own arena, so the forward pass of one micro-batch may
@@ -275,6 +279,14 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             gts = torch.cat([g[2]['gt'] for g in group])
         inputs, gts = gpu_handler.cast_cuda_if_possible([inputs, gts])
 
+        # A batched pass spreads its loss over three places: the class counts of the labels are taken here, in front of the
+        # forward pass (they need no logits), the loss kernel proper sits between the passes, and the loss VALUES - which
+        # only the log reads - are finished and copied to the host behind the backward pass.  Between the passes the
+        # whole chip waits on a chain of small kernels: this takes two of them and the copy out of that chain.
+        staged = None
+        if k > 1 and stage_losses and gts.is_cuda and class_balanced_cross_entropy_loss is _hip_cbce:
+            staged = stage_frames_loss(gts)
+
         outputs = net.forward(inputs)
 
         # (the seed of the backward pass below is announced to the loss: its kernel writes the gradient times 1 / nAveGrad
@@ -287,9 +299,10 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
             losses = loss.detach().reshape(1)
         else:
             # [k]; the sum over frames is taken by the backward seed
-            loss = _losses_per_frame(outputs[-1], gts, (inv_avg_k, 1.0 / avg_grad_every_n) if seeded else None)
+            loss = _losses_per_frame(outputs[-1], gts, (inv_avg_k, 1.0 / avg_grad_every_n) if seeded else None, staged)
             losses = loss.detach()
-        record_losses(group, losses)
+        if staged is None:
+            record_losses(group, losses)
 
         # reference: `loss /= nAveGrad; loss.backward()` (src/train_online.py:92-93).  Seeding the backward pass with
         # 1/nAveGrad is the same gradient (the division's own backward produces exactly this factor) without the
@@ -305,6 +318,9 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         loss.backward(inv_avg if k == 1 else inv_avg_k[:k])
         if last_of_cycle:
             sync.begin()
+        if staged is not None:
+            staged.finish()
+            record_losses(group, losses)
         # (the reference also sums loss.item() into a per-epoch tensorboard scalar, src/train_online.py:94-104: one
         # device sync per frame; the per-pass asynchronous copy above carries the same information without it)
 

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 13
+#define FOSVOS_ABI_VERSION 14
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -268,6 +268,18 @@ size_t fosvos_cbce_workspace_bytes(int64_t numel);
 int fosvos_cbce_loss_frames(const float *logits, const float *label, int64_t frame_numel, int n_frames, int size_average,
                             float grad_scale, float *loss_out, float *grad, void *workspace, size_t workspace_bytes,
                             int device, void *stream);
+/* fosvos_cbce_loss_frames in its three launches, for a caller that has other work to put between them (the online loop):
+ * FOSVOS_CBCE_COUNT needs only the labels (it can run before the forward pass that produces the logits), FOSVOS_CBCE_LOSS
+ * writes grad and the loss partials (the backward pass needs nothing more), FOSVOS_CBCE_FINISH writes loss_out (it can run
+ * behind the backward pass).  `parts` = the stages of this call, run in that order; arguments a stage does not read may
+ * be NULL (COUNT: logits, loss_out, grad; FINISH: logits, label, grad).  The stages of one loss share `workspace`: same
+ * pointer, untouched by anything else in between.  All three in one call = fosvos_cbce_loss_frames, bit for bit. */
+#define FOSVOS_CBCE_COUNT 1
+#define FOSVOS_CBCE_LOSS 2
+#define FOSVOS_CBCE_FINISH 4
+int fosvos_cbce_loss_frames_parts(const float *logits, const float *label, int64_t frame_numel, int n_frames,
+                                  int size_average, float grad_scale, float *loss_out, float *grad, void *workspace,
+                                  size_t workspace_bytes, int parts, int device, void *stream);
 /* The same loss on ONE SHARD of a batch that is split over data-parallel ranks.  The reference counts positives /
  * negatives over the whole batch tensor (src/layers/osvos_layers.py:28-39), so the class weights of a shard must
  * come from the whole batch: batch_counts = DEVICE double[2] {positives, pixels} summed over all shards (the caller

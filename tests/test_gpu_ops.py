@@ -682,6 +682,34 @@ def test_cbce_announced_backward_seed():
     assert torch.equal(fast1, fast[0:1])                       # the batched pass's frame 0 == the frame alone
 
 
+def test_cbce_frames_staged_equals_one_call(ops):
+    """The per-frame loss in three launches with other work in between (count the labels' classes in front of the forward
+    pass, loss + gradient between the passes, loss values behind the backward pass: fosvos_cbce_loss_frames_parts) gives
+    the bits of the one-call form - values and gradients - also through the autograd wrapper the online loop uses."""
+    from layers import osvos_layers as L
+    x = gen(3, 1, 48, 86, seed=76, scale=4.0).to(DEV)
+    y = (gen(3, 1, 48, 86, seed=77) > 0.3).float().to(DEV)
+    want_l, want_g = ops.cbce_loss_frames(x, y, size_average=False, grad_scale=0.2)
+    staged = ops.CbceFramesStaged(y)
+    junk = torch.randn(1 << 20, device=DEV).sum()          # (other kernels and allocations between the stages)
+    got_l, got_g = staged.loss(x, size_average=False, grad_scale=0.2)
+    junk = junk + torch.randn(1 << 20, device=DEV).sum()
+    assert staged.finish() is got_l
+    assert torch.equal(got_l, want_l) and torch.equal(got_g, want_g)
+    # autograd path
+    seed = torch.full((3,), 0.2, device=DEV)
+    xa = x.clone().requires_grad_(True)
+    st = L.stage_frames_loss(y)
+    assert st is not None
+    loss = L.class_balanced_cross_entropy_loss_frames(xa, y, size_average=False, backward_seed=(seed, 0.2), staged=st)
+    loss.backward(seed)
+    st.finish()
+    assert torch.equal(loss.detach(), want_l) and torch.equal(xa.grad, want_g)
+    with pytest.raises(ValueError):
+        L.class_balanced_cross_entropy_loss_frames(xa, y.clone(), size_average=False, staged=st)
+    assert L.stage_frames_loss(y[:, :, :3, :5].contiguous()) is None  # 15 elements per frame: the one-call path
+
+
 # ------------------------------------------------------------------------------------------ SGD
 def test_fused_sgd_zero_grad_flag():
     """step(zero_grad=True) = step() then zero_grad(set_to_none=False), in one pass over the gradients - also for a subset."""
