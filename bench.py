@@ -249,6 +249,102 @@ def offline_config(args, dev, make_frame, barrier):
                         f"(BASELINE.json configs[2]); one iteration is one step"}
 
 
+def _with_steps(args, steps, warmup, fn):
+    saved = args.steps, args.warmup
+    args.steps, args.warmup = steps, warmup
+    try:
+        return fn()
+    finally:
+        args.steps, args.warmup = saved
+
+
+_SAMPLER = r"""
+import os, re, subprocess, sys, time
+exe, path = sys.argv[1], sys.argv[2]
+with open(path, "w") as f:
+    try:
+        txt = subprocess.run([exe, "static", "--limit"], capture_output=True, text=True, timeout=10).stdout
+        m = re.search(r"SOCKET_POWER_LIMIT:\s*(\d+)\s*W", txt)
+        f.write("limit %s\n" % (m.group(1) if m else "-"))
+    except Exception:
+        f.write("limit -\n")
+    f.flush()
+    while True:
+        if not os.path.exists(path + ".go"):  # asleep outside the power window: the other timed regions see no sampler
+            time.sleep(0.05)
+            continue
+        try:
+            txt = subprocess.run([exe, "metric", "--power", "--clock"], capture_output=True, text=True, timeout=10).stdout
+            w = re.search(r"SOCKET_POWER:\s*(\d+)\s*W", txt)
+            clk = [int(m) for m in re.findall(r"GFX_\d+:\s*\n\s*CLK:\s*(\d+)\s*MHz", txt)]
+            if w and clk:
+                f.write("%.3f %s %.1f %d\n" % (time.time(), w.group(1), sum(clk) / len(clk), min(clk)))
+                f.flush()
+        except Exception:
+            pass
+        time.sleep(0.25)
+"""
+
+
+def _start_power_sampler():
+    """A child process that - while the file <path>.go exists - asks amd-smi (read-only) for socket power and GFX clocks
+    four times a second and appends them to a file.  Started BEFORE this process touches the GPU (a process that has initialised the GPU starts no programs);
+    None when amd-smi is not there."""
+    import shutil
+    import tempfile
+    exe = shutil.which("amd-smi") or ("/opt/rocm/bin/amd-smi" if os.path.exists("/opt/rocm/bin/amd-smi") else None)
+    if exe is None:
+        return None
+    fd, path = tempfile.mkstemp(prefix="fosvos_power_", suffix=".txt")
+    os.close(fd)
+    try:
+        proc = subprocess.Popen([sys.executable, "-c", _SAMPLER, exe, path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except OSError:
+        return None
+    return proc, path
+
+
+def _stop_power_sampler(sampler):
+    if sampler is None:
+        return
+    proc, path = sampler
+    proc.terminate()
+    try:
+        proc.wait(timeout=15)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+    for f in (path, path + ".go"):
+        try:
+            os.unlink(f)
+        except OSError:
+            pass
+
+
+def _power_summary(sampler, t_begin, t_end, n_steps, elapsed):
+    """The sampler's lines between the wall-clock times t_begin and t_end."""
+    if sampler is None:
+        return None
+    limit, busy = None, []
+    try:
+        with open(sampler[1]) as f:
+            for line in f:
+                parts = line.split()
+                if parts and parts[0] == "limit":
+                    limit = int(parts[1]) if parts[1].isdigit() else None
+                elif len(parts) == 4 and t_begin <= float(parts[0]) <= t_end:
+                    busy.append((int(parts[1]), float(parts[2]), int(parts[3])))
+    except (OSError, ValueError):
+        return None
+    if len(busy) < 2:
+        return None
+    return {"socket_w_avg": sum(r[0] for r in busy) / len(busy), "socket_w_max": max(r[0] for r in busy),
+            "socket_w_limit": limit, "gfx_mhz_avg": sum(r[1] for r in busy) / len(busy),
+            "gfx_mhz_min_xcd": min(r[2] for r in busy), "samples": len(busy), "steps": n_steps,
+            "value": n_steps / elapsed, "unit": "frames/s",
+            "note": "amd-smi metric --power --clock (a child process started before the GPU was touched) while the shipped "
+                    "step runs for `steps` steps - its own timed window, not the headline's; clocks averaged over the XCDs"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -257,6 +353,13 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or run "
                          f"`python bench.py --gpus {args.gpus}` outside torchrun and let it start its own ranks")
+
+    only_early = os.environ.get("FOSVOS_BENCH_ONLY")
+    power_sampler = None
+    if world == 1 and not args.no_variants and (only_early is None or "power" in only_early.split(",")):
+        power_sampler = _start_power_sampler()
+        import atexit
+        atexit.register(_stop_power_sampler, power_sampler)
 
     import torch
     import torch.distributed as dist
@@ -461,6 +564,23 @@ def main():
         finally:
             args.steps, args.warmup = saved_steps, saved_warm
         out["steps100"] = {"value": 100 / e, "unit": "frames/s", "ms_per_step": e / 100 * 1000.0, "steps": 100, "warmup": 20}
+    if world == 1 and not args.no_variants and want("power"):
+        # What the card reports while the step runs for a few seconds (amd-smi, read-only, once every ~0.3 s from a side
+        # thread; none of it inside the headline's timed region): socket power against its limit and the GFX clocks.
+        # The conv kernels of this step sit at the 1400 W limit when they run back to back (profiles/r04_lab_power_*.txt:
+        # forward alone 1340-1397 W with the clocks down at 1.9-2.0 GHz), so the limit that binds the MFMA phases of
+        # the step is the socket's power, not the matrix pipe's issue rate.
+        if power_sampler is not None:
+            n_power = 4000
+            open(power_sampler[1] + ".go", "w").close()  # wakes the sampler
+            try:
+                e = _with_steps(args, n_power, 10, lambda: timed("power")[0])
+                t_end = time.time()
+            finally:
+                os.unlink(power_sampler[1] + ".go")
+            power = _power_summary(power_sampler, t_end - e, t_end, n_power, e)
+            if power is not None:
+                out["power"] = power
     if world == 1 and not args.no_variants and want("group1"):
         # one frame per pass: the reference's own order, and the worst case of the shape bucketing
         e = timed("group1", env={"FOSVOS_MICROBATCH_GROUP": "1"})[0]
