@@ -29,10 +29,13 @@ import torch
 import torch.distributed as dist
 
 
+SINGLE_RANK_ENV = "FOSVOS_DP_SINGLE_RANK"  # test hook, see collectives_on()
+
+
 def init_distributed(backend: Optional[str] = None) -> bool:
     """Initialise the default process group from the torchrun environment; False when single-process."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and os.environ.get(SINGLE_RANK_ENV) != "1":
         return False
     if dist.is_initialized():
         return True
@@ -46,6 +49,16 @@ def init_distributed(backend: Optional[str] = None) -> bool:
 
 def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def collectives_on() -> bool:
+    """Do the loops run their gradient collectives?  More than one rank - or, as a test hook (FOSVOS_DP_SINGLE_RANK=1 with an
+    initialised process group), a single rank: the all-reduces then run over one rank and change no value, but every
+    stream wait, event and asynchronous work handle of the real backend is exercised.  RCCL needs one device per rank, so
+    this is how the RCCL choreography of the data-parallel step is run on a one-GPU box (tests/test_gpu_parallel.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get(SINGLE_RANK_ENV) == "1"
 
 
 def rank() -> int:
@@ -204,7 +217,7 @@ class FlatGrads:
 
     def all_reduce(self, async_op: bool = False):
         """SUM of the whole buffer over ranks in one collective (no-op in a single process)."""
-        if world_size() == 1:
+        if not collectives_on():
             return None
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
 
@@ -214,7 +227,7 @@ class FlatGrads:
         slice's collective is enqueued with the slice's NATIVE bucket id (`bucket_ids`) and must make the CURRENT stream
         wait for that bucket's gradients (on the HIP path: fosvos_vgg_grad_bucket_wait on the communication stream);
         None = the current stream already follows the whole backward pass."""
-        if world_size() == 1:
+        if not collectives_on():
             return
         for b, (lo, hi) in enumerate(self.slices):
             if wait_bucket is not None:
@@ -258,7 +271,7 @@ class GradSync:
 
     def __init__(self, net, flat: "FlatGrads"):
         self.net, self.flat = net, flat
-        self.active = world_size() > 1
+        self.active = collectives_on()
         self._comm = None
         # Communication timing (COMM_TIMING / FOSVOS_COMM_TIMING=1; GPU only): per optimizer step, events on the
         # communication stream in front of and behind every bucket's all-reduce, an event on the main stream where the data-

@@ -127,6 +127,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     # weights are constant inside an accumulation cycle: let the next forward overlap the wgrad tail of this backward
     net.defer_wgrad_join = os.environ.get('FOSVOS_DEFER_JOIN', '1') != '0'
     world = parallel.world_size() if data_parallel else 1
+    dp_on = data_parallel and parallel.collectives_on()  # (world > 1, or the single-rank test hook)
     local_accum = parallel.split_accumulation(avg_grad_every_n, world)
     # gradients live in one flat fp32 buffer: the wgrad kernels accumulate straight into it, zeroing is one memset,
     # and under data parallelism it is the single all-reduce payload
@@ -308,7 +309,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         # 1/nAveGrad is the same gradient (the division's own backward produces exactly this factor) without the
         # three tiny kernels of the division, the ones-fill and its backward on the critical path
         closes_cycle = (counter_gradient + k) % local_accum == 0
-        last_of_cycle = world > 1 and closes_cycle
+        last_of_cycle = dp_on and closes_cycle
         if hasattr(net, 'last_pass_of_cycle'):
             net.last_pass_of_cycle = closes_cycle
         if last_of_cycle:
@@ -353,7 +354,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
                     # rewrites and repacks weights the closing pass's data-gradient chain on the other stream still reads)
                     wait_side_stream()
                 for b in early_buckets:
-                    if world > 1:
+                    if dp_on:
                         sync.wait_bucket(b)
                     else:
                         net.wait_grad_bucket(flat.bucket_ids[b])
@@ -389,7 +390,7 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         # (measured at 480x854, passes of 1 / 2 / 3+2 frames: +9.4 % / +2.0 % / -2.6 % - a pass of three or more frames does
         # better with its two forward chains side by side, which needs the auxiliary stream the previous pass's weight
         # gradients would still occupy)
-        multi = pass_streams is not None and world == 1 and len(groups) > 1 and max(len(g) for g in groups) <= 2
+        multi = pass_streams is not None and not dp_on and len(groups) > 1 and max(len(g) for g in groups) <= 2
         if multi:
             # both pass streams must see the last optimizer step and the repacked weight images: pack once here, on the
             # caller's stream, instead of inside the first forward pass (which the second stream would have to wait for)

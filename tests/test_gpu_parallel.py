@@ -64,6 +64,41 @@ def _worker(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
+def _worker_one_rccl_rank(port, out_dir):
+    """ONE rank on the real backend (RCCL): parallel.collectives_on()'s test hook keeps the gradient all-reduces - over one
+    rank they change no value, but the communication stream, the bucket events, the asynchronous work handles and the split
+    optimizer step run exactly as they will on eight GPUs (gloo's collectives block the host and hide ordering mistakes)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      FOSVOS_DP_SINGLE_RANK="1")
+    import parallel
+    assert parallel.init_distributed("nccl") and parallel.collectives_on() and parallel.world_size() == 1
+    parallel.COMM_TIMING = True
+    w, _, ret = _train(_frames(), True)
+    torch.save({"w": w, "iterations": ret["iterations"], "comm": ret["comm_timing"]}, os.path.join(out_dir, "rccl1.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_online_dp_choreography_on_one_rccl_rank(tmp_path):
+    p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "rccl1", str(_free_port()), str(tmp_path)])
+    try:
+        assert p.wait(timeout=600) == 0
+    finally:
+        if p.poll() is None:
+            p.kill()
+            p.wait()
+    res = torch.load(os.path.join(str(tmp_path), "rccl1.pt"))
+    assert res["iterations"] == N_FRAMES
+    comm = res["comm"]
+    assert comm is not None and comm["optimizer_steps"] == 2 and comm["comm_exposed_ms_per_step"] >= 0.0
+    assert 59.0e6 < sum(b["bytes"] for b in comm["buckets"]) < 61.5e6
+    assert all(b["end_ms_after_dgrad_end"] > b["start_ms_after_dgrad_end"] for b in comm["buckets"])
+    # a sum over one rank is the identity and the passes are the single-process run's: the same weights, bit for bit
+    ref, _, ret = _train(_frames(), False)
+    assert ret["iterations"] == N_FRAMES
+    for k in ref:
+        assert torch.equal(res["w"][k], ref[k]), k
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -112,4 +147,7 @@ def test_online_dp_on_gpu_equals_single_process(tmp_path):
 
 
 if __name__ == "__main__":
-    _worker(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    if sys.argv[1] == "rccl1":
+        _worker_one_rccl_rank(int(sys.argv[2]), sys.argv[3])
+    else:
+        _worker(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
