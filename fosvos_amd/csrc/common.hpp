@@ -96,6 +96,7 @@ struct HeadBwdArgs {
     void *workspace;
     size_t workspace_bytes;
     int device;
+    int filt_uniform;  // bit s: the 16 per-channel filters of scale s are identical (fosvos_head_fwd)
 };
 int head_bwd_check(const HeadBwdArgs &a);
 int head_bwd_scale(const HeadBwdArgs &a, int s, void *stream);

@@ -59,8 +59,16 @@ template <bool WITH_SIDE_OUT>
 __global__ __launch_bounds__(256) void k_head_fwd(HeadPtrs p, HeadGeom g, const float *__restrict__ dsn_w,
                                                    const float *__restrict__ dsn_b, const float *__restrict__ fuse_w,
                                                    const float *__restrict__ fuse_b, float *__restrict__ fused,
-                                                   float *so0, float *so1, float *so2, float *so3, int H, int W) {
+                                                   float *so0, float *so1, float *so2, float *so3, int H, int W,
+                                                   int umask) {
+    // umask bit s: the 16 per-channel filters of scale s are IDENTICAL (the caller's promise: what interp_surgery writes and
+    // lr 0 keeps, src/layers/osvos_layers.py:70-81, src/util/network_provider.py:154-155).  Then
+    //   sum_c filt[ky][kx][c] fw[c] side[i][j][c] = filt[ky][kx][0] * z[i][j],   z = sum_c fw[c] side[i][j][c]:
+    // the channel contraction is done once per LOW-RES pixel while the window is staged (s_z: one float per pixel) and an
+    // output pixel costs 4 multiply-adds and 4 four-byte LDS reads per scale instead of 64 and 16 sixteen-byte reads (the
+    // general form is bound by LDS bandwidth: 36-44 us for five 480x854 frames on the path between the passes).
     __shared__ __attribute__((aligned(16))) float s_win[hf_off(4)];
+    __shared__ float s_z[hf_off(4) / 16], s_zs[WITH_SIDE_OUT ? hf_off(4) / 16 : 1];
     __shared__ float s_fw[64], s_dw[64];
     const int tid = threadIdx.x;
     const int n = blockIdx.z, Y0 = blockIdx.y * HF_TY, X0 = blockIdx.x * HF_TX;
@@ -68,11 +76,40 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadPtrs p, HeadGeom g, const 
         s_fw[tid] = fuse_w[tid];
         s_dw[tid] = WITH_SIDE_OUT ? dsn_w[tid] : 0.f;
     }
+    if (umask) __syncthreads();  // (the contraction below reads s_fw)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int f = 2 << s, NR = hf_rows(s), NC = hf_cols(s);
         const int i_lo = (Y0 + g.top[s]) / f - 1, j_lo = (X0 + g.left[s]) / f - 1;
         const float4 *sd = reinterpret_cast<const float4 *>(p.side[s] + (int64_t)n * g.hs[s] * g.ws[s] * 16);
+        if ((umask >> s) & 1) {
+            // four consecutive lanes hold the four channel quads of one window pixel (NR * NC * 4 is a multiple of 4 and so
+            // is 256: a group is complete or absent)
+            const float db = WITH_SIDE_OUT ? dsn_b[s] : 0.f;
+            for (int e = tid; e < NR * NC * 4; e += 256) {
+                const int q = e & 3, px = e >> 2;
+                const int r = px / NC, c = px - r * NC;
+                const int i = i_lo + r, j = j_lo + c;
+                const bool in = i >= 0 && i < g.hs[s] && j >= 0 && j < g.ws[s];
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (in) v = sd[((int64_t)i * g.ws[s] + j) * 4 + q];
+                const float *fwq = s_fw + 16 * s + 4 * q, *dwq = s_dw + 16 * s + 4 * q;
+                float d = fwq[0] * v.x + fwq[1] * v.y + fwq[2] * v.z + fwq[3] * v.w;
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                float sc = 0.f;
+                if (WITH_SIDE_OUT) {
+                    sc = dwq[0] * v.x + dwq[1] * v.y + dwq[2] * v.z + dwq[3] * v.w;
+                    sc += __shfl_xor(sc, 1, 64);
+                    sc += __shfl_xor(sc, 2, 64);
+                }
+                if (q == 0) {
+                    s_z[hf_off(s) / 16 + px] = d;
+                    if (WITH_SIDE_OUT) s_zs[hf_off(s) / 16 + px] = in ? sc + db : 0.f;
+                }
+            }
+            continue;
+        }
         // the window is kept as four channel-quad planes [q][pixel]: neighbouring pixels sit 16 B apart, so the taps' reads
         // have no bank conflicts (pixel-major, at a 64-B pitch, 47 % of this kernel's LDS cycles were conflict cycles)
         f32x4 *dst = reinterpret_cast<f32x4 *>(s_win + hf_off(s));
@@ -115,6 +152,31 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadPtrs p, HeadGeom g, const 
         const float *filt = p.filt[s];
         const float *filt1 = WITH_SIDE_OUT ? p.filt1[s] : nullptr;
         const float db = WITH_SIDE_OUT ? dsn_b[s] : 0.f;
+        if ((umask >> s) & 1) {
+            const float *zw = s_z + woff / 16, *zsw = s_zs + (WITH_SIDE_OUT ? woff / 16 : 0);
+            float so_u[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) {
+                const int a = ab >> 1, b = ab & 1;
+                const int i = i1 - a, ky = ky1 + a * f, kx = kx1 + b * f;
+                const float h = filt[(ky * k + kx) * 16];
+                const float f1 = WITH_SIDE_OUT ? filt1[ky * k + kx] : 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int j = (Xo + 16 * m) / f - b;
+                    const int at = (i - i_lo) * NC + (j - j_lo);
+                    out[m] += h * zw[at];
+                    if (WITH_SIDE_OUT) so_u[m] += f1 * zsw[at];
+                }
+            }
+            if (WITH_SIDE_OUT) {
+                float *so = s == 0 ? so0 : s == 1 ? so1 : s == 2 ? so2 : so3;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    if (px_ok[m]) so[idx[m]] = so_u[m];
+            }
+            continue;
+        }
         float fw[16], dw[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -185,7 +247,10 @@ template <> struct HeadTile<1> { static constexpr int TI = 4, TJ = 16, TS = 1; }
 template <> struct HeadTile<2> { static constexpr int TI = 4, TJ = 4, TS = 4; };
 template <> struct HeadTile<3> { static constexpr int TI = 2, TJ = 8, TS = 4; };
 
-template <int S, bool WITH_SIDE_OUT>
+// UNIFORM: the scale's 16 per-channel filters are identical (see k_head_fwd): T_c is ONE number per pixel, the filter is
+// staged as k x k floats instead of k x k x 16 (64 KB at scale 3: one workgroup per CU) and the tap sum is split over all
+// 256 threads as (tap slice u = 4 ts + cq, pixel).
+template <int S, bool WITH_SIDE_OUT, bool UNIFORM>
 __global__ __launch_bounds__(256) void k_head_bwd_scale(const float *__restrict__ side, const float *__restrict__ filt,
                                                          const float *__restrict__ filt1,
                                                          const float *__restrict__ fuse_w16,
@@ -198,8 +263,8 @@ __global__ __launch_bounds__(256) void k_head_bwd_scale(const float *__restrict_
     constexpr int TI = HeadTile<S>::TI, TJ = HeadTile<S>::TJ;
     constexpr int WR = (TI + 1) * f, WC = (TJ + 1) * f;
     extern __shared__ __attribute__((aligned(16))) float smem_h[];
-    float *sF = smem_h;                 // [k*k][16]
-    float *sW = sF + k * k * 16;        // [WR][WC] window of d_fused
+    float *sF = smem_h;                 // [k*k][16]   (UNIFORM: [k*k])
+    float *sW = sF + k * k * (UNIFORM ? 1 : 16);  // [WR][WC] window of d_fused
     float *sW1 = sW + WR * WC;          // [WR][WC] window of d_side_out   (WITH_SIDE_OUT)
     float *sF1 = sW1 + (WITH_SIDE_OUT ? WR * WC : 0);  // [k*k]            (WITH_SIDE_OUT)
     const int tid = threadIdx.x;
@@ -208,7 +273,15 @@ __global__ __launch_bounds__(256) void k_head_bwd_scale(const float *__restrict_
     // Staging: every global load of a thread is issued before the first LDS store (unconditional loads from clamped
     // addresses).  Rolled, these loops waited out one memory round trip per element: 16 + 27 in a row at scale 3,
     // which was the whole 24 us of the kernel.
-    {
+    if constexpr (UNIFORM) {
+        constexpr int FN = k * k, FIT = (FN + 255) / 256;
+        float tf[FIT];
+#pragma unroll
+        for (int it = 0; it < FIT; ++it) tf[it] = filt[(int64_t)min(it * 256 + tid, FN - 1) * 16];  // channel 0 stands for all
+#pragma unroll
+        for (int it = 0; it < FIT; ++it)
+            if (it * 256 + tid < FN) sF[it * 256 + tid] = tf[it];
+    } else {
         constexpr int FN = k * k * 4, FIT = (FN + 255) / 256;
         float4 tf[FIT];
 #pragma unroll
@@ -247,8 +320,11 @@ __global__ __launch_bounds__(256) void k_head_bwd_scale(const float *__restrict_
     // chunk, channels 4 cq .. 4 cq + 3, filter rows ts k / TS .. (ts + 1) k / TS - 1
     constexpr int TS = HeadTile<S>::TS, NPX = TI * TJ, PXC = 64 / TS;
     static_assert(NPX % PXC == 0 && PXC % 16 == 0, "whole chunks; phase 2 walks a chunk 16 pixels at a time");
-    __shared__ __attribute__((aligned(16))) float sP[TS][PXC][16];
-    __shared__ float sG[TS][PXC];
+    __shared__ __attribute__((aligned(16))) float sP[UNIFORM ? 1 : TS][UNIFORM ? 1 : PXC][16];
+    __shared__ float sG[UNIFORM ? 1 : TS][UNIFORM ? 1 : PXC];
+    constexpr int NU = 4 * TS, RU = k / NU;  // UNIFORM: tap slices (filter rows u RU .. u RU + RU - 1) and their partial sums
+    static_assert(k % NU == 0, "whole filter rows per slice");
+    __shared__ float sTu[UNIFORM ? NU : 1][UNIFORM ? PXC : 1], sGu[UNIFORM ? NU : 1][UNIFORM ? PXC : 1];
     const int c = tid & 15, pl = tid >> 4;
     const float fw = fuse_w16[c];
     const float dw = WITH_SIDE_OUT ? dsn_w16[c] : 0.f;
@@ -256,7 +332,37 @@ __global__ __launch_bounds__(256) void k_head_bwd_scale(const float *__restrict_
 #pragma unroll 1
     for (int p0 = 0; p0 < NPX; p0 += PXC) {
     if (p0) __syncthreads();  // the previous chunk's partial sums have been read
-    {
+    if constexpr (UNIFORM) {
+        const int cq = tid & 3, pl1 = (tid >> 2) % PXC, ts = tid / (4 * PXC), u = 4 * ts + cq;
+        const int il = (p0 + pl1) / TJ, jl = (p0 + pl1) - il * TJ;
+        const float *wp = sW + il * f * WC + jl * f;
+        const float *wp1 = sW1 + il * f * WC + jl * f;
+        float T1 = 0.f, G1 = 0.f;
+#pragma unroll
+        for (int ky = u * RU; ky < (u + 1) * RU; ++ky) {
+            if constexpr (S >= 1) {
+#pragma unroll
+                for (int kx = 0; kx < k; kx += 4) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wp + ky * WC + kx);
+                    const float4 h4 = *reinterpret_cast<const float4 *>(sF + ky * k + kx);
+                    T1 += h4.x * w4.x + h4.y * w4.y + h4.z * w4.z + h4.w * w4.w;
+                    if (WITH_SIDE_OUT) {
+                        const float4 v4 = *reinterpret_cast<const float4 *>(wp1 + ky * WC + kx);
+                        G1 += sF1[ky * k + kx] * v4.x + sF1[ky * k + kx + 1] * v4.y + sF1[ky * k + kx + 2] * v4.z +
+                              sF1[ky * k + kx + 3] * v4.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int kx = 0; kx < k; ++kx) {
+                    T1 += sF[ky * k + kx] * wp[ky * WC + kx];
+                    if (WITH_SIDE_OUT) G1 += sF1[ky * k + kx] * wp1[ky * WC + kx];
+                }
+            }
+        }
+        sTu[u][pl1] = T1;
+        if (WITH_SIDE_OUT) sGu[u][pl1] = G1;
+    } else {
         const int cq = tid & 3, pl1 = (tid >> 2) % PXC, ts = tid / (4 * PXC);
         const int il = (p0 + pl1) / TJ, jl = (p0 + pl1) - il * TJ;
         const float *wp = sW + il * f * WC + jl * f;
@@ -303,11 +409,23 @@ __global__ __launch_bounds__(256) void k_head_bwd_scale(const float *__restrict_
         const int il = p / TJ, jl = p - il * TJ;
         const int i = i0 + il, j = j0 + jl;
         if (i >= hs || j >= ws) continue;
-        float T = sP[0][pc][c], G = WITH_SIDE_OUT ? sG[0][pc] : 0.f;
+        float T, G;
+        if constexpr (UNIFORM) {
+            T = sTu[0][pc];
+            G = WITH_SIDE_OUT ? sGu[0][pc] : 0.f;
 #pragma unroll
-        for (int ts = 1; ts < TS; ++ts) {
-            T += sP[ts][pc][c];
-            if (WITH_SIDE_OUT) G += sG[ts][pc];
+            for (int u = 1; u < NU; ++u) {
+                T += sTu[u][pc];
+                if (WITH_SIDE_OUT) G += sGu[u][pc];
+            }
+        } else {
+            T = sP[0][pc][c];
+            G = WITH_SIDE_OUT ? sG[0][pc] : 0.f;
+#pragma unroll
+            for (int ts = 1; ts < TS; ++ts) {
+                T += sP[ts][pc][c];
+                if (WITH_SIDE_OUT) G += sG[ts][pc];
+            }
         }
         const int64_t pix = ((int64_t)n * hs + i) * ws + j;
         const float sv = side[pix * 16 + c];
@@ -345,18 +463,18 @@ struct HeadBwdLaunch {
     static int blocks(int N, int hs, int ws) {
         return (int)(cdiv(ws, HeadTile<S>::TJ) * cdiv(hs, HeadTile<S>::TI) * N);
     }
-    template <bool SO>
+    template <bool SO, bool UNI>
     static size_t lds_bytes() {
         constexpr int f = 2 << S, k = 4 << S;
         constexpr int WR = (HeadTile<S>::TI + 1) * f, WC = (HeadTile<S>::TJ + 1) * f;
-        return sizeof(float) * (size_t)(k * k * 16 + WR * WC * (SO ? 2 : 1) + (SO ? k * k : 0));
+        return sizeof(float) * (size_t)(k * k * (UNI ? 1 : 16) + WR * WC * (SO ? 2 : 1) + (SO ? k * k : 0));
     }
-    template <bool SO>
+    template <bool SO, bool UNI>
     static int run(const float *side, const float *filt, const float *filt1, const float *fw16, const float *dw16,
                    const float *d_fused, const float *d_so, uint16_t *d_side, float *slabs, int N, int hs, int ws,
                    int top, int left, int H, int W, hipStream_t st) {
-        const size_t lds = lds_bytes<SO>();
-        auto kern = k_head_bwd_scale<S, SO>;
+        const size_t lds = lds_bytes<SO, UNI>();
+        auto kern = k_head_bwd_scale<S, SO, UNI>;
         if (lds > 64 * 1024)
             FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -410,7 +528,18 @@ __global__ __launch_bounds__(768) void k_head_finish(FinishArgs fa, float *__res
     }
     const int col = threadIdx.x % 48, g = threadIdx.x / 48;
     double acc = 0.0;
-    for (int b = g; b < fa.n_slabs[s]; b += 16) acc += (double)fa.slabs[s][(int64_t)b * 48 + col];
+    // eight slabs in flight per thread, added in the same order as one at a time (a rolled loop paid one memory round trip
+    // per slab: 131 in a row at scale 0 with five frames - the whole 50 us of this kernel, at the head of the
+    // weight-gradient stream)
+    const int n_slabs = fa.n_slabs[s];
+    for (int b0 = g; b0 < n_slabs; b0 += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fa.slabs[s][(int64_t)min(b0 + 16 * j, n_slabs - 1) * 48 + col];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (b0 + 16 * j < n_slabs) acc += (double)v[j];
+    }
     red[g][col] = acc;
     __syncthreads();
     if (g != 0) return;
@@ -429,7 +558,7 @@ constexpr int kBiasBlocks = 512;
 extern "C" int fosvos_head_fwd(const float *const side[4], const int hs[4], const int ws[4],
                                const float *const filt[4], const float *const filt1[4], const float *dsn_w,
                                const float *dsn_b, const float *fuse_w, const float *fuse_b, float *fused,
-                               float *const side_out[4], int N, int H, int W, int device, void *stream) {
+                               float *const side_out[4], int N, int H, int W, int filt_uniform, int device, void *stream) {
     FOSVOS_REQUIRE(side && hs && ws && filt && fuse_w && fuse_b && fused, FOSVOS_E_ARG, "head_fwd: null pointer");
     FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0, FOSVOS_E_SHAPE, "head_fwd: bad shape N=%d H=%d W=%d", N, H, W);
     const bool with_so = side_out && side_out[0];
@@ -453,10 +582,11 @@ extern "C" int fosvos_head_fwd(const float *const side[4], const int hs[4], cons
     FOSVOS_PROF("k_head_fwd", stream, 0.0);
     if (with_so)
         hipLaunchKernelGGL(k_head_fwd<true>, grid, dim3(256), 0, (hipStream_t)stream, p, g, dsn_w, dsn_b, fuse_w, fuse_b,
-                           fused, side_out[0], side_out[1], side_out[2], side_out[3], H, W);
+                           fused, side_out[0], side_out[1], side_out[2], side_out[3], H, W, filt_uniform & 15);
     else
         hipLaunchKernelGGL(k_head_fwd<false>, grid, dim3(256), 0, (hipStream_t)stream, p, g, dsn_w, dsn_b, fuse_w, fuse_b,
-                           fused, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, H, W);
+                           fused, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, H, W,
+                           filt_uniform & 15);
     FOSVOS_LAUNCH_CHECK();
     return FOSVOS_OK;
 }
@@ -487,10 +617,10 @@ extern "C" int fosvos_head_bwd(const float *const side[4], const int hs[4], cons
                                const float *const filt[4], const float *const filt1[4], const float *dsn_w,
                                const float *fuse_w, const float *d_fused, const float *const d_side_out[4],
                                uint16_t *const d_side[4], float *d_fuse_w, float *d_fuse_b, float *d_dsn_w,
-                               float *d_dsn_b, int N, int H, int W, void *workspace, size_t workspace_bytes, int device,
-                               void *stream) {
+                               float *d_dsn_b, int N, int H, int W, int filt_uniform, void *workspace,
+                               size_t workspace_bytes, int device, void *stream) {
     const HeadBwdArgs a{side, hs, ws, filt, filt1, dsn_w, fuse_w, d_fused, d_side_out, d_side, d_fuse_w, d_fuse_b,
-                        d_dsn_w, d_dsn_b, N, H, W, 0, workspace, workspace_bytes, device};
+                        d_dsn_w, d_dsn_b, N, H, W, 0, workspace, workspace_bytes, device, filt_uniform & 15};
     if (int rc = head_bwd_check(a)) return rc;
     for (int s = 0; s < 4; ++s)
         if (int rc = head_bwd_scale(a, s, stream)) return rc;
@@ -538,14 +668,14 @@ int fosvos::head_bwd_scale(const HeadBwdArgs &a, int s, void *stream) {
     const float *f1 = with_so ? a.filt1[s] : nullptr;
     const float *dw16 = with_so ? a.dsn_w + 16 * s : nullptr;
     const float *dso = with_so ? a.d_side_out[s] : nullptr;
+    const bool uni = (a.filt_uniform >> s) & 1;
+#define FOSVOS_HEAD_RUN(SS, SO_, UNI_)                                                                                \
+    HeadBwdLaunch<SS>::run<SO_, UNI_>(a.side[s], a.filt[s], f1, a.fuse_w + 16 * s, dw16, a.d_fused, dso, a.d_side[s],   \
+                                      wsf + off[s], a.N, a.hs[s], a.ws[s], g.top[s], g.left[s], a.H, a.W, st)
 #define FOSVOS_HEAD_CASE(SS)                                                                                          \
     case SS:                                                                                                          \
-        return with_so ? HeadBwdLaunch<SS>::run<true>(a.side[s], a.filt[s], f1, a.fuse_w + 16 * s, dw16, a.d_fused, dso, \
-                                                      a.d_side[s], wsf + off[s], a.N, a.hs[s], a.ws[s], g.top[s],       \
-                                                      g.left[s], a.H, a.W, st)                                         \
-                       : HeadBwdLaunch<SS>::run<false>(a.side[s], a.filt[s], f1, a.fuse_w + 16 * s, dw16, a.d_fused, dso, \
-                                                       a.d_side[s], wsf + off[s], a.N, a.hs[s], a.ws[s], g.top[s],      \
-                                                       g.left[s], a.H, a.W, st);
+        return with_so ? (uni ? FOSVOS_HEAD_RUN(SS, true, true) : FOSVOS_HEAD_RUN(SS, true, false))                   \
+                       : (uni ? FOSVOS_HEAD_RUN(SS, false, true) : FOSVOS_HEAD_RUN(SS, false, false));
     switch (s) {
         FOSVOS_HEAD_CASE(0)
         FOSVOS_HEAD_CASE(1)
@@ -553,6 +683,7 @@ int fosvos::head_bwd_scale(const HeadBwdArgs &a, int s, void *stream) {
         FOSVOS_HEAD_CASE(3)
     }
 #undef FOSVOS_HEAD_CASE
+#undef FOSVOS_HEAD_RUN
     return FOSVOS_OK;
 }
 

@@ -206,8 +206,8 @@ int forward_impl(hipEvent_t *ev, const fosvos_vgg_weights *w, const float *frame
                     if (side_out && side_out[i]) soh[i] = side_out[i] + (size_t)f0 * H * W;
                 }
                 FOSVOS_TRY(fosvos_head_fwd(sideh, hsh, wsh, w->filt, w->filt1, w->dsn_w, w->dsn_b, w->fuse_w, w->fuse_b,
-                                           fused + (size_t)f0 * H * W, (side_out && side_out[0]) ? soh : nullptr, nf, H, W, device,
-                                           half ? sa : sm));
+                                           fused + (size_t)f0 * H * W, (side_out && side_out[0]) ? soh : nullptr, nf, H, W,
+                                           w->filt_uniform, device, half ? sa : sm));
             }
         }
         if (par) {
@@ -262,7 +262,7 @@ int forward_impl(hipEvent_t *ev, const fosvos_vgg_weights *w, const float *frame
         wsz[i] = a.sw[i + 1];
     }
     return fosvos_head_fwd(side, hs, wsz, w->filt, w->filt1, w->dsn_w, w->dsn_b, w->fuse_w, w->fuse_b, fused, side_out, N, H,
-                           W, device, stream);
+                           W, w->filt_uniform, device, stream);
 }
 }  // namespace
 
@@ -343,7 +343,7 @@ extern "C" int fosvos_vgg_backward(fosvos_ctx *ctx, const fosvos_vgg_weights *w,
     const HeadBwdArgs ha{side, hs, wsz, w->filt, with_so ? w->filt1 : nullptr, with_so ? w->dsn_w : nullptr, w->fuse_w,
                          d_fused, with_so ? d_side_out : nullptr, dside, g->fuse_w, g->fuse_b,
                          with_so ? g->dsn_w : nullptr, with_so ? g->dsn_b : nullptr, N, H, W, acc, base + a.hws,
-                         a.hws_bytes, device};
+                         a.hws_bytes, device, w->filt_uniform & 15};
     FOSVOS_TRY(head_bwd_check(ha));
     // Only d_side[3] is needed right away (stage 5 runs first): it stays on the data-gradient stream.  The three
     // larger scales and the fuse / score_dsn weight gradients go to the wgrad stream; the data-gradient stream picks

@@ -17,7 +17,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
 LIB_PATH = os.environ.get("FOSVOS_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 CONV_RELU = 1
 CONV_OUT_F32 = 2
 
@@ -40,7 +40,8 @@ class VggWeights(ctypes.Structure):
     """fosvos_vgg_weights (include/fosvos_hip.h): device pointers, struct itself in host memory."""
     _fields_ = [("conv_w", _P13), ("conv_b", _P13), ("conv_wf", _P13), ("conv_wd", _P13),
                 ("side_b", _P4), ("side_wf", _P4), ("side_wd", _P4), ("filt", _P4), ("filt1", _P4),
-                ("dsn_w", c_void_p), ("dsn_b", c_void_p), ("fuse_w", c_void_p), ("fuse_b", c_void_p)]
+                ("dsn_w", c_void_p), ("dsn_b", c_void_p), ("fuse_w", c_void_p), ("fuse_b", c_void_p),
+                ("filt_uniform", c_int)]
 
 
 class VggGrads(ctypes.Structure):
@@ -127,10 +128,10 @@ SIGNATURES = {
                                            c_void_p]),
     "fosvos_head_fwd": (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_void_p),
                                 POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                POINTER(c_void_p), c_int, c_int, c_int, c_int, c_void_p]),
+                                POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fosvos_head_bwd": (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_void_p),
                                 POINTER(c_void_p), c_void_p, c_void_p, c_void_p, POINTER(c_void_p),
-                                POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_void_p, c_size_t, c_int, c_void_p]),
     "fosvos_head_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "fosvos_cbce_loss": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t,

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import ops
@@ -54,6 +56,7 @@ class PackedWeights:
 
     def __init__(self) -> None:
         self._cache: Dict[str, Tuple[Tuple[int, int], object]] = {}
+        self._uniform: Dict[str, bool] = {}  # deconv filter name -> its channel filters are identical (deconv_diag)
         self.arenas = ArenaPool()
 
     @staticmethod
@@ -113,7 +116,24 @@ class PackedWeights:
                     f"implements the per-channel (diagonal) form the reference initialises and freezes")
         diag = diag.permute(1, 2, 0).contiguous()  # [k,k,C]
         self._cache[name] = (key, diag)
+        # (the same sync as the off-diagonal check above, once per weight version): are the C channel filters identical?
+        self._uniform[name] = bool((diag == diag[..., :1]).all().item())
         return diag
+
+    def head_uniform_mask(self, P: Dict[str, torch.Tensor]) -> int:
+        """Bit s: upscale[s]'s 16 channel filters are identical - interp_surgery's bilinear filters, which the optimizers
+        never move (lr 0) - so the head kernels may contract the channels before the upsampling (fosvos_head_fwd's
+        ``filt_uniform``).  Checked on the weights themselves whenever they change; FOSVOS_HEAD_UNIFORM=0 switches the
+        fast path off (A/B)."""
+        if os.environ.get("FOSVOS_HEAD_UNIFORM", "1") == "0":
+            return 0
+        mask = 0
+        for i in range(4):
+            name = f"upscale.{i}.weight"
+            self.deconv_diag(name, P[name])
+            if self._uniform.get(name, False):
+                mask |= 1 << i
+        return mask
 
 
 def _conv_list():
@@ -132,7 +152,8 @@ CONVS = _conv_list()
 
 
 class Saved:
-    __slots__ = ("frame", "conv_in", "conv_out", "pool_in", "feats", "side", "H", "W", "with_side_out", "filt", "filt1")
+    __slots__ = ("frame", "conv_in", "conv_out", "pool_in", "feats", "side", "H", "W", "with_side_out", "filt", "filt1",
+                 "filt_uniform")
 
 
 def forward(P: Dict[str, torch.Tensor], packs: PackedWeights, x: torch.Tensor, with_side_out: bool = True,
@@ -182,8 +203,11 @@ def forward(P: Dict[str, torch.Tensor], packs: PackedWeights, x: torch.Tensor, w
     dsn_b = torch.cat([P[f"score_dsn.{i}.bias"].detach().reshape(1) for i in range(4)]).contiguous()
     fuse_w = P["fuse.weight"].detach().reshape(64).contiguous()
     fuse_b = P["fuse.bias"].detach().reshape(1).contiguous()
-    fused, side_out = ops.head_fwd(side, filt, filt1, dsn_w, dsn_b, fuse_w, fuse_b, H, W, with_side_out=with_side_out)
+    umask = packs.head_uniform_mask(P)
+    fused, side_out = ops.head_fwd(side, filt, filt1, dsn_w, dsn_b, fuse_w, fuse_b, H, W, with_side_out=with_side_out,
+                                   filt_uniform=umask)
     if keep:
+        sv.filt_uniform = umask
         sv.frame = x
         sv.conv_in, sv.conv_out, sv.pool_in, sv.feats, sv.side = conv_in, conv_out, pool_in, feats, side
         sv.H, sv.W, sv.with_side_out = H, W, with_side_out
@@ -230,7 +254,8 @@ def backward(P: Dict[str, torch.Tensor], packs: PackedWeights, sv: "Saved", d_ou
     d_side, d_fuse_w, d_fuse_b, d_dsn_w, d_dsn_b = ops.head_bwd(
         sv.side, sv.filt, sv.filt1 if with_so else None, dsn_w if with_so else None, fuse_w,
         d_fused.contiguous().float() if d_fused is not None else None,
-        [g.contiguous().float() for g in d_so] if with_so else None, sv.H, sv.W)
+        [g.contiguous().float() for g in d_so] if with_so else None, sv.H, sv.W,
+        filt_uniform=getattr(sv, "filt_uniform", 0))
     grads["fuse.weight"] = d_fuse_w.reshape(1, 64, 1, 1)
     grads["fuse.bias"] = d_fuse_b
     if with_so:
@@ -443,6 +468,7 @@ def _weights_struct(P: Dict[str, torch.Tensor], packs: PackedWeights):
     dsn_b = packs.small("dsn_b", [P[f"score_dsn.{i}.bias"] for i in range(4)])
     w.dsn_w, w.dsn_b = dsn_w.data_ptr(), dsn_b.data_ptr()
     w.fuse_w, w.fuse_b = P["fuse.weight"].data_ptr(), P["fuse.bias"].data_ptr()
+    w.filt_uniform = packs.head_uniform_mask(P)
     keep += [dsn_w, dsn_b]
     return w, keep
 

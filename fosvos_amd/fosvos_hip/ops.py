@@ -403,9 +403,10 @@ def maxpool_bwd(x: torch.Tensor, dy: torch.Tensor, relu_mask: bool = True) -> to
 # ------------------------------------------------------------------------------------------ head
 def head_fwd(side: Sequence[torch.Tensor], filt: Sequence[torch.Tensor], filt1: Optional[Sequence[torch.Tensor]],
              dsn_w: Optional[torch.Tensor], dsn_b: Optional[torch.Tensor], fuse_w: torch.Tensor, fuse_b: torch.Tensor,
-             H: int, W: int, with_side_out: bool = True):
+             H: int, W: int, with_side_out: bool = True, filt_uniform: int = 0):
     """side[s]: fp32 NHWC [N,hs,ws,16]; filt[s]: [k,k,16]; filt1[s]: [k,k]; dsn_w [4,16]; dsn_b [4];
-    fuse_w [64]; fuse_b [1].  Returns (fused [N,1,H,W], [4 side outputs] or None)."""
+    fuse_w [64]; fuse_b [1].  Returns (fused [N,1,H,W], [4 side outputs] or None).
+    filt_uniform: bit s = the caller has checked that filt[s]'s 16 channel filters are identical (``filters_uniform_mask``)."""
     n = side[0].shape[0]
     for s in range(4):
         _need(side[s], _F32, "head_fwd side"); _need(filt[s], _F32, "head_fwd filt")
@@ -431,14 +432,25 @@ def head_fwd(side: Sequence[torch.Tensor], filt: Sequence[torch.Tensor], filt1: 
                                 int_array4([t.shape[2] for t in side]), ptr_array4([t.data_ptr() for t in filt]),
                                 ptr_array4(f1_ptrs), _p(dsn_w) if with_side_out else None,
                                 _p(dsn_b) if with_side_out else None, fuse_w.data_ptr(), fuse_b.data_ptr(),
-                                fused.data_ptr(), ptr_array4(so_ptrs), n, H, W, dev, st), "head_fwd")
+                                fused.data_ptr(), ptr_array4(so_ptrs), n, H, W, int(filt_uniform) & 15, dev, st), "head_fwd")
     _pe(t0, "head_fwd", 2.0 * n * H * W * 256, 4 * (sum(t.numel() for t in side) + n * H * W * (5 if with_side_out else 1)))
     return fused, outs
 
 
+def filters_uniform_mask(filt: Sequence[torch.Tensor]) -> int:
+    """Bit s set where filt[s] ([k,k,16], the diagonal of upscale[s].weight) holds the SAME k x k filter in all 16 channels,
+    element for element - the promise head_fwd / head_bwd's ``filt_uniform`` asks for.  One device sync: call it when the
+    weights change, not per step (engine.PackedWeights caches it with the filters)."""
+    mask = 0
+    for s, f in enumerate(filt):
+        if bool((f == f[..., :1]).all().item()):
+            mask |= 1 << s
+    return mask
+
+
 def head_bwd(side: Sequence[torch.Tensor], filt: Sequence[torch.Tensor], filt1: Optional[Sequence[torch.Tensor]],
              dsn_w: Optional[torch.Tensor], fuse_w: torch.Tensor, d_fused: Optional[torch.Tensor],
-             d_side_out: Optional[Sequence[torch.Tensor]], H: int, W: int):
+             d_side_out: Optional[Sequence[torch.Tensor]], H: int, W: int, filt_uniform: int = 0):
     """Returns (d_side[4] bf16 NHWC [N,hs,ws,32], d_fuse_w[64], d_fuse_b[1], d_dsn_w[4,16]|None, d_dsn_b[4]|None)."""
     n = side[0].shape[0]
     dev_t = side[0].device
@@ -466,7 +478,8 @@ def head_bwd(side: Sequence[torch.Tensor], filt: Sequence[torch.Tensor], filt1: 
                             int_array4([t.shape[2] for t in side]), ptr_array4([t.data_ptr() for t in filt]),
                             ptr_array4(f1_ptrs), _p(dsn_w) if with_so else None, fuse_w.data_ptr(), _p(d_fused),
                             ptr_array4(dso_ptrs), ptr_array4([t.data_ptr() for t in d_side]), d_fuse_w.data_ptr(),
-                            d_fuse_b.data_ptr(), _p(d_dsn_w), _p(d_dsn_b), n, H, W, ws, wsn, dev, st), "head_bwd")
+                            d_fuse_b.data_ptr(), _p(d_dsn_w), _p(d_dsn_b), n, H, W, int(filt_uniform) & 15, ws, wsn, dev, st),
+          "head_bwd")
     _pe(t0, "head_bwd", 2.0 * n * H * W * 256, 4 * (sum(t.numel() for t in side) + n * H * W * (5 if with_so else 1)) +
         2 * sum(t.numel() for t in d_side))
     return d_side, d_fuse_w, d_fuse_b, d_dsn_w, d_dsn_b

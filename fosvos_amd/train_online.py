@@ -320,6 +320,9 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         if last_of_cycle:
             sync.begin()
         if staged is not None:
+            # the loss VALUES: one small kernel and the copy to the host, behind the backward pass.  (Queued on the
+            # communication stream instead, behind an event, they cost 0.6 % - a third stream with work in flight - where on
+            # this stream they cost nothing measurable: profiles/r04_lab_step_ab_head_loss.txt.)
             staged.finish()
             record_losses(group, losses)
         # (the reference also sums loss.item() into a per-epoch tensorboard scalar, src/train_online.py:94-104: one

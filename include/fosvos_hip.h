@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 14
+#define FOSVOS_ABI_VERSION 15
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -228,12 +228,18 @@ int fosvos_maxpool2x2_ceil_bwd(const uint16_t *x, const uint16_t *dy, uint16_t *
  * up_s is the transposed conv with the DIAGONAL of upscale[s].weight, passed channel-fastest as
  * filt[s] = [k][k][16] fp32 (one k x k filter per channel); up1_s uses filt1[s] = [k][k].  crop is the
  * reference's centre crop (floor(d/2) leading pixels removed).
+ * filt_uniform: bit s set = the caller PROMISES that the 16 channel filters of filt[s] are identical, element for element
+ * (what interp_surgery writes - src/layers/osvos_layers.py:70-81 - and the optimizers keep: lr 0,
+ * src/util/network_provider.py:110-111,154-155).  The kernels then contract the channels once per low-resolution pixel
+ * and apply ONE k x k filter (same sums in another order; 16x fewer multiply-adds and LDS reads).  0 = the general form.
+ * A set bit with filters that differ between channels evaluates channel 0's filter for all: the check is the caller's.
  * replaces: upscale[s], upscale_[s], score_dsn[s], center_crop, torch.cat and fuse
  *           (src/networks/osvos_vgg.py:69-82, src/layers/osvos_layers.py:47-54). */
 int fosvos_head_fwd(const float *const side[4], const int hs[4], const int ws[4], const float *const filt[4],
                     const float *const filt1[4], const float *dsn_w /*[4][16]*/, const float *dsn_b /*[4]*/,
                     const float *fuse_w /*[64]*/, const float *fuse_b /*[1]*/, float *fused,
-                    float *const side_out[4] /* all NULL or all set */, int N, int H, int W, int device, void *stream);
+                    float *const side_out[4] /* all NULL or all set */, int N, int H, int W, int filt_uniform, int device,
+                    void *stream);
 /* Backward of the above.
  *   d_fused [N,1,H,W] fp32 or NULL;  d_side_out[s] [N,1,H,W] fp32 or NULL (all or none)
  *   d_side[s]   bf16 NHWC [N,hs,ws,32]: channels 0..15 = gradient wrt side[s], 16..31 = 0 (the
@@ -244,8 +250,8 @@ int fosvos_head_fwd(const float *const side[4], const int hs[4], const int ws[4]
 int fosvos_head_bwd(const float *const side[4], const int hs[4], const int ws[4], const float *const filt[4],
                     const float *const filt1[4], const float *dsn_w, const float *fuse_w, const float *d_fused,
                     const float *const d_side_out[4], uint16_t *const d_side[4], float *d_fuse_w, float *d_fuse_b,
-                    float *d_dsn_w, float *d_dsn_b, int N, int H, int W, void *workspace, size_t workspace_bytes,
-                    int device, void *stream);
+                    float *d_dsn_w, float *d_dsn_b, int N, int H, int W, int filt_uniform /* as fosvos_head_fwd */,
+                    void *workspace, size_t workspace_bytes, int device, void *stream);
 size_t fosvos_head_bwd_workspace_bytes(int N, int H, int W);
 
 /* ---- class-balanced BCE-with-logits, loss and gradient in one call ----------------------------
@@ -434,6 +440,7 @@ typedef struct fosvos_vgg_weights {
     const float *dsn_b;           /* [4] */
     const float *fuse_w;          /* [64] */
     const float *fuse_b;          /* [1] */
+    int filt_uniform;             /* bit s: filt[s]'s 16 channel filters are identical (see fosvos_head_fwd) */
 } fosvos_vgg_weights;
 
 typedef struct fosvos_vgg_grads {

@@ -582,6 +582,55 @@ def _head_ref(side, up, up1, dsn_w, dsn_b, fuse_w, fuse_b, H, W):
     return outs + [fused]
 
 
+@pytest.mark.parametrize("n,H,W,uniform", [(1, 48, 86, 0b1111), (2, 61, 107, 0b0101), (1, 33, 47, 0b1010), (3, 17, 16, 0b1000)])
+def test_head_channel_uniform_filters(ops, n, H, W, uniform):
+    """filt_uniform: where a scale's 16 channel filters are identical (what interp_surgery writes and lr 0 keeps,
+    src/layers/osvos_layers.py:70-81) the head kernels contract the channels before the upsampling.  Against the torch
+    reference (conv_transpose2d + crop + cat + 1x1, autograd) and against the general kernels on the same inputs - forward
+    with and without side outputs, backward with all five upstream gradients and with the fused one only - for masks that mix
+    uniform and per-channel scales."""
+    side, up, up1, dsn_w, dsn_b, fuse_w, fuse_b = _head_inputs(n, H, W, seed=52)
+    for i in range(4):
+        if (uniform >> i) & 1:  # the same k x k filter (channel 3's, noise and all) on the whole diagonal
+            for c in range(16):
+                up[i][c, c] = up[i][3, 3]
+    leaves = [s.clone().requires_grad_(True) for s in side]
+    dw_l, db_l = dsn_w.clone().requires_grad_(True), dsn_b.clone().requires_grad_(True)
+    fw_l, fb_l = fuse_w.clone().requires_grad_(True), fuse_b.clone().requires_grad_(True)
+    ref = _head_ref(leaves, up, up1, dw_l, db_l, fw_l, fb_l, H, W)
+    dev = lambda t: t.contiguous().to(DEV)
+    side_d = [dev(s.permute(0, 2, 3, 1)) for s in side]
+    idx = torch.arange(16)
+    filt = [dev(u[idx, idx].permute(1, 2, 0)) for u in up]
+    filt1 = [dev(u[0, 0]) for u in up1]
+    assert ops.filters_uniform_mask(filt) == uniform
+    args = (side_d, filt, filt1, dev(dsn_w), dev(dsn_b), dev(fuse_w), dev(fuse_b), H, W, True)
+    fused, so = ops.head_fwd(*args, filt_uniform=uniform)
+    fused_g, so_g = ops.head_fwd(*args, filt_uniform=0)
+    assert rel_err(fused.cpu(), ref[4].detach()) < 1e-5 and rel_err(fused, fused_g) < 2e-6
+    for i in range(4):
+        assert rel_err(so[i].cpu(), ref[i].detach()) < 1e-5 and rel_err(so[i], so_g[i]) < 2e-6, f"side_out {i}"
+    fused_only, _ = ops.head_fwd(side_d, filt, None, None, None, dev(fuse_w), dev(fuse_b), H, W, False, filt_uniform=uniform)
+    assert rel_err(fused_only, fused) < 1e-6
+    g = [gen(n, 1, H, W, seed=64 + i) for i in range(5)]
+    torch.autograd.backward(ref, g)
+    bargs = (side_d, filt, filt1, dev(dsn_w), dev(fuse_w), dev(g[4]), [dev(t) for t in g[:4]], H, W)
+    d_side, d_fw, d_fb, d_dw, d_db = ops.head_bwd(*bargs, filt_uniform=uniform)
+    d_side_g, d_fw_g, d_fb_g, d_dw_g, d_db_g = ops.head_bwd(*bargs, filt_uniform=0)
+    for i in range(4):
+        got = d_side[i].float().cpu()
+        assert torch.equal(got[..., 16:], torch.zeros_like(got[..., 16:]))
+        assert_bf16_close(got[..., :16].permute(0, 3, 1, 2), leaves[i].grad, f"d_side {i}")
+        assert rel_err(d_side[i].float(), d_side_g[i].float()) < 4e-3  # (two bf16 roundings of nearly equal fp32 sums)
+    for got, gen_, want in ((d_fw, d_fw_g, fw_l.grad), (d_fb, d_fb_g, fb_l.grad), (d_dw, d_dw_g, dw_l.grad), (d_db, d_db_g, db_l.grad)):
+        assert rel_err(got.cpu(), want) < 2e-5 and rel_err(got, gen_) < 1e-5
+    d_side2, d_fw2, d_fb2, a, b = ops.head_bwd(side_d, filt, None, None, dev(fuse_w), dev(g[4]), None, H, W, filt_uniform=uniform)
+    d_side2_g, d_fw2_g, _, _, _ = ops.head_bwd(side_d, filt, None, None, dev(fuse_w), dev(g[4]), None, H, W)
+    assert a is None and b is None and rel_err(d_fw2, d_fw2_g) < 1e-5
+    for i in range(4):
+        assert rel_err(d_side2[i].float(), d_side2_g[i].float()) < 4e-3
+
+
 @pytest.mark.parametrize("n,H,W", [(1, 48, 86), (2, 61, 107), (1, 33, 47), (1, 17, 16)])
 def test_head_fwd_bwd(ops, n, H, W):
     side, up, up1, dsn_w, dsn_b, fuse_w, fuse_b = _head_inputs(n, H, W, seed=50)
