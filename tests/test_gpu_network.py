@@ -587,8 +587,9 @@ def test_scheduling_switches_do_not_change_the_weights(monkeypatch):
     frames = [O.synthetic_frame(1, 40, 70, seed=90 + i) for i in range(5)]
     loader = [{"image": x, "gt": gt} for x, gt in frames]
     runs = {}
-    for tag, env in (("default", {}), ("one_step", {"FOSVOS_SPLIT_STEP": "0"}), ("one_stream_fwd", {"FOSVOS_FWD_AUX": "0"})):
-        for k_, v_ in (("FOSVOS_SPLIT_STEP", "1"), ("FOSVOS_FWD_AUX", "1")):
+    for tag, env in (("default", {}), ("one_step", {"FOSVOS_SPLIT_STEP": "0"}), ("one_stream_fwd", {"FOSVOS_FWD_AUX": "0"}),
+                     ("staged_loss", {"FOSVOS_STAGE_LOSS": "1"}), ("general_head", {"FOSVOS_HEAD_UNIFORM": "0"})):
+        for k_, v_ in (("FOSVOS_SPLIT_STEP", "1"), ("FOSVOS_FWD_AUX", "1"), ("FOSVOS_STAGE_LOSS", "0"), ("FOSVOS_HEAD_UNIFORM", "1")):
             monkeypatch.setenv(k_, env.get(k_, v_))
         net, _ = make_net(23)
         prov = VGGOnlineProvider.__new__(VGGOnlineProvider)
@@ -600,11 +601,26 @@ def test_scheduling_switches_do_not_change_the_weights(monkeypatch):
         assert ret["iterations"] == 10
         runs[tag] = ({n_: p.detach().clone() for n_, p in net.named_parameters()}, ret["loss"])
     base_w, base_loss = runs["default"]
-    for tag in ("one_step", "one_stream_fwd"):
+    # ... and the loss of a batched pass in three stages around the passes (FOSVOS_STAGE_LOSS=1: class counts in front of the
+    # forward pass, values behind the backward pass) is the same loss
+    for tag in ("one_step", "one_stream_fwd", "staged_loss"):
         w, loss = runs[tag]
         assert loss == base_loss, tag
         for n_ in base_w:
             assert torch.equal(w[n_], base_w[n_]), (tag, n_)
+    # the head's general kernels against the channel-contracted ones the bilinear upscale filters select: the same sums in
+    # another order - the two runs stay within rounding of each other, they are not bit-identical
+    # Bit-identical logits are not to be expected (measured: the losses of the first cycle agree to 1e-7).  From there the two
+    # runs are two samples of the bf16 backward chain's own noise - a gradient image whose fp32 value moved by 1e-6 rounds to
+    # the other bf16 neighbour now and then, 13 layers deep - which is what GRAD tolerances everywhere in this file are
+    # about: the updates differ by ~1 % of their norm (measured 0.7-1.0 %), the losses behind the first step by <= 0.6 %.
+    w, loss = runs["general_head"]
+    assert np.allclose(loss[:5], base_loss[:5], rtol=1e-5) and np.allclose(loss, base_loss, rtol=2e-2)
+    w0 = {n_: p.detach().clone() for n_, p in make_net(23)[0].named_parameters()}
+    for n_ in base_w:
+        step = (base_w[n_] - w0[n_]).double().norm().item()
+        diff = (base_w[n_] - w[n_]).double().norm().item()
+        assert diff <= 0.05 * step + 1e-12, (n_, diff, step)
 
 
 @pytest.mark.parametrize("case", ["two_pairs", "two_singles", "cycle_over_two_windows"])
