@@ -329,8 +329,73 @@ __global__ __launch_bounds__(256) void k_head_bwd_scale(const float *__restrict_
     const float fw = fuse_w16[c];
     const float dw = WITH_SIDE_OUT ? dsn_w16[c] : 0.f;
     float a = 0.f, b = 0.f, g = 0.f;
+    // DIRECT (scale 0, one filter for all channels: 16 taps, the most pixels): thread (pixel, channel half) takes the whole
+    // tap sum itself - no partial sums, no barriers - reads its 8 side values as two 16-byte loads and writes its 8
+    // gradients (and 8 padding zeros) as 16-byte stores.  (One thread per (pixel, channel) stored 2 bytes per lane: 50-56 us
+    // for five frames at the head of the weight-gradient stream, against ~75 MB of traffic.)
+    constexpr bool DIRECT = UNIFORM && S == 0;
+    __shared__ float red[4][3][16];
+    if constexpr (DIRECT) {
+        const int h8 = (tid & 1) * 8, pl2 = tid >> 1;
+        float fw8[8], dw8[8], a8[8], b8[8], g1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            fw8[e] = fuse_w16[h8 + e];
+            dw8[e] = WITH_SIDE_OUT ? dsn_w16[h8 + e] : 0.f;
+            a8[e] = 0.f;
+            b8[e] = 0.f;
+        }
+        for (int p = pl2; p < NPX; p += 128) {
+            const int il = p / TJ, jl = p - il * TJ;
+            const int i = i0 + il, j = j0 + jl;
+            if (i >= hs || j >= ws) continue;
+            const float *wp = sW + il * f * WC + jl * f;
+            const float *wp1 = sW1 + il * f * WC + jl * f;
+            float T = 0.f, G = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < k; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < k; ++kx) {
+                    T += sF[ky * k + kx] * wp[ky * WC + kx];
+                    if (WITH_SIDE_OUT) G += sF1[ky * k + kx] * wp1[ky * WC + kx];
+                }
+            const int64_t pix = ((int64_t)n * hs + i) * ws + j;
+            const float4 s0 = *reinterpret_cast<const float4 *>(side + pix * 16 + h8);
+            const float4 s1 = *reinterpret_cast<const float4 *>(side + pix * 16 + h8 + 4);
+            const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            float ds[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ds[e] = fw8[e] * T + dw8[e] * G;
+                a8[e] += sv[e] * T;
+                if (WITH_SIDE_OUT) b8[e] += sv[e] * G;
+            }
+            if (WITH_SIDE_OUT && h8 == 0) g1 += G;
+            *reinterpret_cast<uint4 *>(d_side + pix * 32 + h8) = pack8(ds);           // channels 8 h .. 8 h + 7
+            *reinterpret_cast<uint4 *>(d_side + pix * 32 + 16 + h8) = make_uint4(0, 0, 0, 0);  // ... and their padding twins
+        }
+        // sums over the 32 pixel lanes of a wave (lanes of equal parity), then across the waves through `red`
+#pragma unroll
+        for (int o = 2; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a8[e] += __shfl_xor(a8[e], o, 64);
+                if (WITH_SIDE_OUT) b8[e] += __shfl_xor(b8[e], o, 64);
+            }
+            if (WITH_SIDE_OUT) g1 += __shfl_xor(g1, o, 64);
+        }
+        const int wave_d = tid >> 6, lane_d = tid & 63;
+        if (lane_d < 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[wave_d][0][8 * lane_d + e] = a8[e];
+                red[wave_d][1][8 * lane_d + e] = b8[e];
+                red[wave_d][2][8 * lane_d + e] = (lane_d == 0 && e == 0) ? g1 : 0.f;
+            }
+        }
+    }
 #pragma unroll 1
-    for (int p0 = 0; p0 < NPX; p0 += PXC) {
+    for (int p0 = 0; p0 < (DIRECT ? 0 : NPX); p0 += PXC) {
     if (p0) __syncthreads();  // the previous chunk's partial sums have been read
     if constexpr (UNIFORM) {
         const int cq = tid & 3, pl1 = (tid >> 2) % PXC, ts = tid / (4 * PXC), u = 4 * ts + cq;
@@ -440,15 +505,16 @@ __global__ __launch_bounds__(256) void k_head_bwd_scale(const float *__restrict_
     }
     }  // chunks
     // block reduction over lanes with equal c: xor 16, 32 inside the wave, then LDS across waves
-    a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-    b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-    g += __shfl_xor(g, 16, 64); g += __shfl_xor(g, 32, 64);
-    __shared__ float red[4][3][16];
-    const int wave = tid >> 6, lane = tid & 63;
-    if (lane < 16) {
-        red[wave][0][lane] = a;
-        red[wave][1][lane] = b;
-        red[wave][2][lane] = g;
+    if constexpr (!DIRECT) {
+        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+        g += __shfl_xor(g, 16, 64); g += __shfl_xor(g, 32, 64);
+        const int wave = tid >> 6, lane = tid & 63;
+        if (lane < 16) {
+            red[wave][0][lane] = a;
+            red[wave][1][lane] = b;
+            red[wave][2][lane] = g;
+        }
     }
     __syncthreads();
     if (tid < 48) {
