@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -226,9 +227,44 @@ void run32(const char *name, int wg_per_cu, float *out, int chunks = 64) {
            MODE == 2 ? 0.0 : tf / 2500.0, 100.0 * st[0] / st[1]);
 }
 
-int main() {
+// `mfma_lds_lab sustain [seconds]`: the igemm-like loop, then the MFMA-only loop, each for `seconds` (default 6) of
+// back-to-back 10-ms launches, one line per second - run it under tools/smi_probe.sh to see what the card sustains at its
+// power limit (the 50-ms measurements above end before the power controller has pulled the clocks down).
+template <int MODE>
+void sustain(const char *name, float *out, double seconds) {
+    const int grid = 256 * 2 * 4, lds = 160 * 1024 / 2 - 1024, chunks = 1024;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_loop<4, 4, MODE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    double total_ms = 0;
+    while (total_ms < seconds * 1e3) {
+        const int reps = 100;
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_loop<4, 4, MODE, 2>), dim3(grid), dim3(256), lds, 0, out, chunks);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        total_ms += ms;
+        const double flops = (double)reps * grid * 4 * chunks * 9 * 16 * (16.0 * 16 * 32 * 2);
+        unsigned long long st[2];
+        CK(hipMemcpy(st, reinterpret_cast<char *>(out) + (60 << 20), 16, hipMemcpyDeviceToHost));
+        printf("%-18s t=%5.1f s  %7.1f TFLOP/s (%.3f of 2500)  in-kernel clock %.0f MHz\n", name, total_ms * 1e-3,
+               flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / 2500.0, 100.0 * st[0] / st[1]);
+        fflush(stdout);
+    }
+}
+
+int main(int argc, char **argv) {
     float *out;
     CK(hipMalloc(&out, 64 << 20));
+    if (argc > 1 && !strcmp(argv[1], "sustain")) {
+        const double seconds = argc > 2 ? atof(argv[2]) : 6.0;
+        sustain<0>("igemm-like 64x64", out, seconds);
+        sustain<1>("mfma only 64x64", out, seconds);
+        return 0;
+    }
     run<4, 4, 1, 2>("mfma only 64x64", 2, out);
     run<4, 4, 1, 1>("mfma only 64x64", 1, out);
     run<4, 4, 2, 2>("lds only 64x64", 2, out);
