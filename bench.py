@@ -565,11 +565,10 @@ def main():
             args.steps, args.warmup = saved_steps, saved_warm
         out["steps100"] = {"value": 100 / e, "unit": "frames/s", "ms_per_step": e / 100 * 1000.0, "steps": 100, "warmup": 20}
     if world == 1 and not args.no_variants and want("power"):
-        # What the card reports while the step runs for a few seconds (amd-smi, read-only, once every ~0.3 s from a side
-        # thread; none of it inside the headline's timed region): socket power against its limit and the GFX clocks.
-        # The conv kernels of this step sit at the 1400 W limit when they run back to back (profiles/r04_lab_power_*.txt:
-        # forward alone 1340-1397 W with the clocks down at 1.9-2.0 GHz), so the limit that binds the MFMA phases of
-        # the step is the socket's power, not the matrix pipe's issue rate.
+        # What the card reports while the step runs for a few seconds (amd-smi, read-only, four times a second from a child
+        # process; none of it inside the headline's timed region): socket power against its limit and the GFX clocks.
+        # Context (profiles/r04_lab_power_clocks.txt): the forward / data-gradient kernels ALONE sit at the 1400 W limit
+        # with the clocks at 1.9-2.1 GHz, while the bare LDS-fed MFMA loop sustains 0.78 of peak at 1255 W.
         if power_sampler is not None:
             n_power = 4000
             open(power_sampler[1] + ".go", "w").close()  # wakes the sampler
