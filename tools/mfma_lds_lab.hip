@@ -227,6 +227,138 @@ void run32(const char *name, int wg_per_cu, float *out, int chunks = 64) {
            MODE == 2 ? 0.0 : tf / 2500.0, 100.0 * st[0] / st[1]);
 }
 
+// ---- who issues the memory instructions?  The igemm-like loop again (64 x 64 per wave), but per chunk of nine taps each
+// MFMA wave's share of the conv kernels' memory work has to be issued by SOMEONE: ND LDS-DMA loads of 1 KB (global -> a scratch
+// LDS area nobody reads) and NS stores of 1 KB.  MEM = 0: nobody (the plain loop); 1: the MFMA waves themselves, spread
+// between the taps - what k_conv3x3_igemm / k_conv3x3_pp do; 2: four extra PRODUCER waves per workgroup that do nothing else
+// (512 threads: wave w + 4 issues for MFMA wave w).  One workgroup per CU in all three (the producer form needs the
+// registers of the second wave slot), so MEM = 0 is the lone-wave-per-SIMD ceiling.
+typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void lab_dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigned lds_dst, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+template <int MEM, int ND, int NS, bool SHARED_SRC = false>
+__global__ __launch_bounds__(MEM == 2 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(MEM == 2 ? 2 : 1, MEM == 2 ? 2 : 1)))
+void k_mem(float *out, const uint4 *src, uint4 *dst, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    constexpr int MF = 4, NF = 4, TW = 32, HALO_W = TW + 2, NPIX_PAD = ((4 * MF * 16 / TW + 2) * HALO_W + 3 + 15) / 16 * 16, BN = 16 * NF;
+    uint4 *sA = smem, *sB = smem + 4 * NPIX_PAD;
+    constexpr int SCRATCH = 4 * NPIX_PAD + 12 * BN;  // uint4 index where the DMA scratch area starts (4 waves x ND KB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = tid; i < SCRATCH; i += blockDim.x) {
+        unsigned h = (i + 1) * 2654435761u;
+        uint4 v;
+        h ^= h >> 15; h *= 2246822519u; v.x = (h & 0x807f807fu) | 0x3f803f80u;
+        h ^= h >> 13; h *= 3266489917u; v.y = (h & 0x807f807fu) | 0x3f803f80u;
+        h ^= h >> 16; h *= 668265263u; v.z = (h & 0x807f807fu) | 0x3f803f80u;
+        h ^= h >> 15; h *= 374761393u; v.w = (h & 0x807f807fu) | 0x3f803f80u;
+        smem[i] = v;
+    }
+    __syncthreads();
+    // this wave's slice of the global buffers: workgroup b, MFMA wave w -> 64 KB of src (walked round robin) and of dst
+    const int mw = __builtin_amdgcn_readfirstlane(wave & 3);
+    const auto s_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(src), 0, 0x7fffffff, 0x00020000);
+    const auto d_rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0x7fffffff, 0x00020000);
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)((blockIdx.x * 4 + mw) * 65536u));
+    const unsigned lds_scratch = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)(smem + SCRATCH) + mw * ND * 1024u);
+    auto mem_op = [&](int cc, int slot) {  // slot 0 .. ND + NS - 1 of chunk cc
+        const unsigned off = __builtin_amdgcn_readfirstlane(base + (unsigned)(((cc * (ND + NS) + slot) & 63) * 1024u));
+        if (slot < ND) lab_dma16(s_rsrc, lds_scratch + slot * 1024u, lane * 16u, SHARED_SRC ? (off & 0xffffu) : off);
+        else __builtin_amdgcn_raw_buffer_store_b128(u32x4{(unsigned)cc, (unsigned)slot, (unsigned)lane, 0u}, d_rsrc, lane * 16u, off, 0);
+    };
+    if (MEM == 2 && wave >= 4) {  // a producer wave: the memory instructions of MFMA wave (wave - 4), paced by chunk count only
+        for (int cc = 0; cc < chunks; ++cc) {
+#pragma unroll
+            for (int slot = 0; slot < ND + NS; ++slot) mem_op(cc, slot);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // (stays a few instructions ahead, never unboundedly)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    int a_base[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int pb = (wave * MF + i) * 16;
+        a_base[i] = (lane >> 4) * NPIX_PAD + (pb / TW) * HALO_W + pb % TW + (lane & 15);
+    }
+    const int b_base = (lane >> 4) * BN + (lane & 15);
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[MF], bfr[2][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) af[i] = __builtin_bit_cast(bf16x8, sA[a_base[i]]);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) bfr[0][j] = bfr[1][j] = __builtin_bit_cast(bf16x8, sB[b_base + j * 16]);
+    for (int cc = 0; cc < chunks; ++cc) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int nt = (tap + 1) % 9;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tap & 1][j], af[i], acc[i][j], 0, 0, 0);
+                af[i] = __builtin_bit_cast(bf16x8, sA[a_base[i] + (nt / 3) * HALO_W + nt % 3]);
+                bfr[(tap + 1) & 1][i] = __builtin_bit_cast(bf16x8, sB[b_base + (nt % 3) * 4 * BN + i * 16]);
+            }
+            if (MEM == 1) {  // this wave's memory instructions, dealt out between the taps
+#pragma unroll
+                for (int slot = tap; slot < ND + NS; slot += 9) mem_op(cc, slot);
+            }
+        }
+        if (MEM == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    if (MEM == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 12345.678f) out[blockIdx.x * 256 + tid] = s;
+    if (blockIdx.x == 0 && tid == 0) {
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(out + (60 << 20) / 4);
+        st[0] = __builtin_amdgcn_s_memtime() - c0;
+        st[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+
+template <int MEM, int ND, int NS, bool SHARED_SRC = false>
+void run_mem(const char *name, float *out, const uint4 *src, uint4 *dst, int chunks = 1024) {
+    const int grid = 256, lds = 150 * 1024;  // one workgroup per CU
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mem<MEM, ND, NS, SHARED_SRC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int threads = MEM == 2 ? 512 : 256;
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_mem<MEM, ND, NS, SHARED_SRC>), dim3(grid), dim3(threads), lds, 0, out, src, dst, chunks);
+    CK(hipDeviceSynchronize());
+    const int reps = 20;
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_mem<MEM, ND, NS, SHARED_SRC>), dim3(grid), dim3(threads), lds, 0, out, src, dst, chunks);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)reps * grid * 4 * chunks * 9 * 16 * (16.0 * 16 * 32 * 2);
+    const double bytes = (double)reps * grid * 4 * chunks * (ND + NS) * 1024.0;
+    unsigned long long st[2];
+    CK(hipMemcpy(st, reinterpret_cast<char *>(out) + (60 << 20), 16, hipMemcpyDeviceToHost));
+    // (workgroup 0's first MFMA wave stamps its own life: with producer waves the launch lasts as long as THEIR traffic takes)
+    const double wave_ms = st[1] / 100.0 * 1e-3;
+    printf("%-44s ND=%2d NS=%d  launch %7.3f ms  %7.1f TFLOP/s (%.3f)  memory instr. %5.2f TB/s  |  MFMA wave 0 alive %7.3f ms = %7.1f "
+           "TFLOP/s at its rate  clock %.0f MHz\n", name, ND, NS, ms / reps, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / 2500.0,
+           MEM ? bytes / (ms * 1e-3) / 1e12 : 0.0, wave_ms, flops / reps / (wave_ms * 1e-3) / 1e12, 100.0 * st[0] / st[1]);
+}
+
 // `mfma_lds_lab sustain [seconds]`: the igemm-like loop, then the MFMA-only loop, each for `seconds` (default 6) of
 // back-to-back 10-ms launches, one line per second - run it under tools/smi_probe.sh to see what the card sustains at its
 // power limit (the 50-ms measurements above end before the power controller has pulled the clocks down).
@@ -259,6 +391,24 @@ void sustain(const char *name, float *out, double seconds) {
 int main(int argc, char **argv) {
     float *out;
     CK(hipMalloc(&out, 64 << 20));
+    if (argc > 1 && !strcmp(argv[1], "mem")) {
+        uint4 *src, *dst;
+        CK(hipMalloc(&src, 256u * 4 * 65536));
+        CK(hipMalloc(&dst, 256u * 4 * 65536));
+        CK(hipMemset(src, 1, 256u * 4 * 65536));
+        run_mem<0, 10, 6>("no memory instructions (1 wave / SIMD)", out, src, dst);
+        run_mem<1, 10, 6>("MFMA waves issue them (as the conv kernels)", out, src, dst);
+        run_mem<2, 10, 6>("four producer waves issue them", out, src, dst);
+        run_mem<1, 5, 3>("MFMA waves issue them, half the traffic", out, src, dst);
+        run_mem<2, 5, 3>("four producer waves, half the traffic", out, src, dst);
+        run_mem<1, 10, 0, true>("MFMA waves: loads only, L2-resident source", out, src, dst);
+        run_mem<2, 10, 0, true>("producer waves: loads only, L2-resident", out, src, dst);
+        run_mem<1, 10, 3, true>("MFMA waves: L2 loads + 3 stores", out, src, dst);
+        run_mem<2, 10, 3, true>("producer waves: L2 loads + 3 stores", out, src, dst);
+        run_mem<1, 10, 0>("MFMA waves: loads only", out, src, dst);
+        run_mem<1, 0, 6>("MFMA waves: stores only", out, src, dst);
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "sustain")) {
         const double seconds = argc > 2 ? atof(argv[2]) : 6.0;
         sustain<0>("igemm-like 64x64", out, seconds);
