@@ -43,9 +43,13 @@ __device__ __forceinline__ Split split_bf16(float v) {
     return Split{h, f2bf(v - bf2f(h))};
 }
 
+// relu_bits (may be null): the ReLU mask of y as one bit per element, [N,H,W,8] bytes - bit e of byte g = channel 8 g + e
+// is > 0 - for the data gradient of the NEXT conv (fosvos_conv3x3_dgrad_bits), which at 480x854 is bound by HBM traffic and
+// otherwise reads all 128 bytes of every pixel of y only to test their signs.
 __global__ __launch_bounds__(256) void k_first_fwd(const float *__restrict__ frame, const float *__restrict__ w,
-                                                    const float *__restrict__ bias, uint16_t *__restrict__ y, int N,
-                                                    int H, int W, int tiles_x, int tiles_y) {
+                                                    const float *__restrict__ bias, uint16_t *__restrict__ y,
+                                                    uint8_t *__restrict__ relu_bits, int N, int H, int W, int tiles_x,
+                                                    int tiles_y) {
     __shared__ __attribute__((aligned(16))) char s_x[2 * BUF_BYTES];  // two tiles (double buffer) x {hi, lo} images
     __shared__ float s_w[CO * 27];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -171,6 +175,14 @@ __global__ __launch_bounds__(256) void k_first_fwd(const float *__restrict__ fra
                 uint16_t *dst = y + (((int64_t)n * H + gy) * W + gx) * CO + 16 * kg;
                 *reinterpret_cast<uint4 *>(dst) = o0;
                 *reinterpret_cast<uint4 *>(dst + 8) = o1;
+                if (relu_bits) {  // from the STORED values (post-ReLU, so > 0 is != 0): this lane's 16 channels = two bytes
+                    const unsigned wds[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+                    unsigned m = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        m |= ((wds[e] & 0xffffu) ? 1u : 0u) << (2 * e) | ((wds[e] >> 16) ? 1u : 0u) << (2 * e + 1);
+                    *reinterpret_cast<uint16_t *>(relu_bits + (((int64_t)n * H + gy) * W + gx) * (CO / 8) + 2 * kg) = (uint16_t)m;
+                }
             }
         }
         if (next < n_tiles) store_tile(nxt);  // image `nxt` was last read in the previous iteration (barrier below)
@@ -195,6 +207,11 @@ extern "C" int fosvos_conv3x3_first_plan(int N, int H, int W, int *tiles, int *w
 
 extern "C" int fosvos_conv3x3_first_fwd(const float *frame, const float *w, const float *bias, uint16_t *y, int N,
                                         int H, int W, int Co, int device, void *stream) {
+    return fosvos_conv3x3_first_fwd_bits(frame, w, bias, y, nullptr, N, H, W, Co, device, stream);
+}
+
+extern "C" int fosvos_conv3x3_first_fwd_bits(const float *frame, const float *w, const float *bias, uint16_t *y,
+                                             uint8_t *relu_bits, int N, int H, int W, int Co, int device, void *stream) {
     FOSVOS_REQUIRE(frame && w && bias && y, FOSVOS_E_ARG, "conv3x3_first_fwd: null pointer");
     FOSVOS_REQUIRE(Co == CO, FOSVOS_E_SHAPE, "conv3x3_first_fwd: Co=%d, only %d is built", Co, CO);
     FOSVOS_REQUIRE(N > 0 && H > 0 && W > 0 && N <= 65535, FOSVOS_E_SHAPE, "conv3x3_first_fwd: bad shape N=%d H=%d W=%d",
@@ -205,8 +222,8 @@ extern "C" int fosvos_conv3x3_first_fwd(const float *frame, const float *w, cons
     FOSVOS_REQUIRE(tiles < 0x7fffffffLL, FOSVOS_E_SHAPE, "conv3x3_first_fwd: too many tiles");
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, kFirstMaxWorkgroups);
     FOSVOS_PROF("k_first_fwd", stream, 2.0 * N * H * W * 27 * Co);
-    hipLaunchKernelGGL(k_first_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, frame, w, bias, y, N, H, W, tiles_x,
-                       tiles_y);
+    hipLaunchKernelGGL(k_first_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, frame, w, bias, y, relu_bits, N, H, W,
+                       tiles_x, tiles_y);
     FOSVOS_LAUNCH_CHECK();
     return FOSVOS_OK;
 }

@@ -39,6 +39,7 @@ struct ConvArgs {
     const uint16_t *w;         // packed [Cin/32][9][4][Co_pad][8]
     const float *bias;         // [Cout] or null
     const uint16_t *relu_src;  // [N,H,W,Cout] or null
+    const uint8_t *relu_bits;  // the same mask as one BIT per element ([N,H,W,Cout/8] bytes, bit e of a byte = channel 8 g + e > 0) or null
     const uint16_t *addend;    // [N,H,W,Cout] or null
     void *y;                   // [N,H,W,Cout] bf16 (or fp32)
     uint16_t *y_pool;          // optional [N,ceil(H/2),ceil(W/2),Cout] bf16: 2x2 ceil-mode max pool of y, same launch
@@ -396,11 +397,29 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
         const bool ok = it * T::NT + tid < OUT_N && gy < H && o_gx < W;
         voff[it] = ok ? ((gy * W + o_gx) * a.Cout + n0 + o_cg * 8) * 2 : -1;
     }
-    const bool masked = (a.relu_src || a.addend) && !(a.flags & kSubsample2);
+    const bool masked = (a.relu_src || a.relu_bits || a.addend) && !(a.flags & kSubsample2);
     uint4 mk[OUT_IT], ad[OUT_IT];
 #pragma unroll
     for (int it = 0; it < OUT_IT; ++it) mk[it] = ad[it] = make_uint4(0, 0, 0, 0);
-    if (masked) {
+    if (masked && a.relu_bits) {
+        // the ReLU mask as bits: one byte per 16-byte vector of the bf16 image, expanded to the 0 / 1 halfwords that
+        // keep_where_pos_bf16x8 tests (an HBM-bound data gradient - conv1_2's - reads 8 instead of 128 bytes per pixel)
+        auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.relu_bits + (int64_t)n * H * W * (a.Cout >> 3)), 0,
+                                                        img_bytes >> 4, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < OUT_IT; ++it) {
+            const unsigned b = __builtin_amdgcn_raw_buffer_load_b8(b_rsrc, voff[it] < 0 ? -1 : voff[it] >> 4, 0, 0);
+            mk[it] = make_uint4((b & 1u) | ((b & 2u) << 15), ((b >> 2) & 1u) | ((b & 8u) << 13), ((b >> 4) & 1u) | ((b & 32u) << 11),
+                                ((b >> 6) & 1u) | ((b & 128u) << 9));
+        }
+        if (a.addend) {
+            auto ad_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.addend + (int64_t)n * H * W * a.Cout), 0,
+                                                             img_bytes, 0x00020000);
+#pragma unroll
+            for (int it = 0; it < OUT_IT; ++it)
+                ad[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ad_rsrc, voff[it], 0, 0));
+        }
+    } else if (masked) {
         auto m_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint16_t *>(a.relu_src ? a.relu_src + (int64_t)n * H * W * a.Cout : yo), 0,
             a.relu_src ? img_bytes : 0, 0x00020000);
@@ -444,7 +463,7 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
 #pragma unroll
             for (int it = 0; it < OUT_IT; ++it) {
                 uint4 v = *reinterpret_cast<const uint4 *>(s_vec + it * PIX_STEP * T::OUT_LD);
-                if (a.relu_src) v = keep_where_pos_bf16x8(v, mk[it]);  // the ReLU mask, on the packed pairs
+                if (a.relu_src || a.relu_bits) v = keep_where_pos_bf16x8(v, mk[it]);  // the ReLU mask, on the packed pairs
                 if (a.addend || (a.flags & kReluAfterAdd)) {
                     float f[8];
                     unpack8(v, f);
@@ -575,10 +594,15 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(const ConvArgs a, int64
             *reinterpret_cast<float4 *>(yo + 4) = make_float4(f[4], f[5], f[6], f[7]);
             continue;
         }
-        if (a.relu_src || a.addend) {
+        if (a.relu_src || a.relu_bits || a.addend) {
             // same rounding sequence as the fused epilogue: round, mask, add, round
             uint4 v = pack8(f);
             unpack8(v, f);
+            if (a.relu_bits) {
+                const unsigned b = a.relu_bits[off >> 3];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = ((b >> e) & 1u) ? f[e] : 0.f;
+            }
             if (a.relu_src) {
                 float m[8];
                 unpack8(*reinterpret_cast<const uint4 *>(a.relu_src + off), m);
@@ -908,6 +932,18 @@ extern "C" int fosvos_conv3x3_fwd_pool(const uint16_t *x, const uint16_t *w_pack
     a.x = x; a.w = w_packed; a.bias = bias; a.relu_src = nullptr; a.addend = nullptr; a.y = y; a.y_pool = y_pool;
     a.N = N; a.H = H; a.W = W; a.Cin = roundup(Ci, 32); a.Cout = Co; a.Co_pad = roundup(Co, 16); a.flags = flags;
     return dispatch(a, Ci, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int fosvos_conv3x3_dgrad_bits(const uint16_t *dy, const uint16_t *w_dgrad_packed, const uint8_t *relu_bits,
+                                         const uint16_t *addend, uint16_t *dx, int N, int H, int W, int Ci, int Co,
+                                         void *workspace, size_t workspace_bytes, int device, void *stream) {
+    if (int rc = check_common(dy, w_dgrad_packed, dx, N, H, W, Co, Ci, "conv3x3_dgrad_bits")) return rc;
+    FOSVOS_REQUIRE(relu_bits && Ci % 8 == 0, FOSVOS_E_ARG, "conv3x3_dgrad_bits: null mask or Ci=%d not a multiple of 8", Ci);
+    FOSVOS_ENTER(device);
+    ConvArgs a{};
+    a.x = dy; a.w = w_dgrad_packed; a.bias = nullptr; a.relu_src = nullptr; a.relu_bits = relu_bits; a.addend = addend; a.y = dx;
+    a.N = N; a.H = H; a.W = W; a.Cin = roundup(Co, 32); a.Cout = Ci; a.Co_pad = roundup(Ci, 16); a.flags = 0;
+    return dispatch(a, Co, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int fosvos_conv3x3_dgrad(const uint16_t *dy, const uint16_t *w_dgrad_packed, const uint16_t *relu_src,

@@ -30,6 +30,7 @@ struct Arena {
     size_t gpooled[4];       // gradients wrt them
     size_t side[4];          // fp32 NHWC [N,h,w,16]
     size_t dside[4];         // bf16 NHWC [N,h,w,32]
+    size_t bits0;            // the ReLU mask of conv1_1's output as bits, [N,H,W,8] bytes (conv1_2's data gradient reads it)
     size_t ws, ws_bytes;     // op workspace of the main stream (split-K slabs)
     size_t hws, hws_bytes;   // head backward slabs (written from both streams, so never shared with `ws`)
     // per-layer slab workspaces of the wgrad (auxiliary) stream: every layer's slabs stay live until the batched
@@ -57,6 +58,7 @@ Arena make_arena(int N, int H, int W) {
         a.side[s - 1] = take((size_t)N * a.sh[s] * a.sw[s] * 16 * 4);
         a.dside[s - 1] = take((size_t)N * a.sh[s] * a.sw[s] * 32 * 2);
     }
+    a.bits0 = take((size_t)N * H * W * (kCout[0] / 8));
     a.hws_bytes = up256(fosvos_head_bwd_workspace_bytes(N, H, W));
     a.hws = take(a.hws_bytes);
     size_t ws = 256;
@@ -161,8 +163,9 @@ int forward_impl(hipEvent_t *ev, const fosvos_vgg_weights *w, const float *frame
                 void *wsc = half ? base + a.wsa_conv[c] : ws;
                 const size_t wsn = half ? a.wsa_conv_bytes[c] : a.ws_bytes;
                 if (c == 0) {
-                    FOSVOS_TRY(fosvos_conv3x3_first_fwd(frame + (size_t)f0 * 3 * H * W, w->conv_w[0], w->conv_b[0], yc, nf, H, W,
-                                                        kCout[0], device, st));
+                    FOSVOS_TRY(fosvos_conv3x3_first_fwd_bits(frame + (size_t)f0 * 3 * H * W, w->conv_w[0], w->conv_b[0], yc,
+                                                             reinterpret_cast<uint8_t *>(base + a.bits0) + (size_t)f0 * px * (kCout[0] / 8),
+                                                             nf, H, W, kCout[0], device, st));
                 } else {
                     if (c == kFirstOfStage[s]) {
                         const size_t ppx = (size_t)a.sh[s] * a.sw[s];
@@ -220,7 +223,8 @@ int forward_impl(hipEvent_t *ev, const fosvos_vgg_weights *w, const float *frame
     for (int c = 0; c < kNConv; ++c) {
         const int s = kStageOf[c];
         if (c == 0) {
-            FOSVOS_TRY(fosvos_conv3x3_first_fwd(frame, w->conv_w[0], w->conv_b[0], act(0), N, H, W, kCout[0], device, stream));
+            FOSVOS_TRY(fosvos_conv3x3_first_fwd_bits(frame, w->conv_w[0], w->conv_b[0], act(0),
+                                                     reinterpret_cast<uint8_t *>(base + a.bits0), N, H, W, kCout[0], device, stream));
         } else {
             if (c == kFirstOfStage[s])  // stage entry: the pooled map the previous stage's last conv wrote
                 x = reinterpret_cast<uint16_t *>(base + a.pooled[s - 1]);
@@ -397,8 +401,13 @@ extern "C" int fosvos_vgg_backward(fosvos_ctx *ctx, const fosvos_vgg_weights *w,
                 FOSVOS_TRY(wgrad_impl(xin, gact(c), g->conv_w[c], g->conv_b[c], N, hh, ww, kCin[c], kCout[c], acc,
                                       base + a.wsa_conv[c], a.wsa_conv_bytes[c], device, sa,
                                       (offload && s == 1) ? &reduce_m : &reduce, tail && s <= tail_stages));
-            FOSVOS_TRY(fosvos_conv3x3_dgrad(gact(c), w->conv_wd[c], mask, nullptr, dx, N, hh, ww, kCin[c], kCout[c], ws,
-                                            a.ws_bytes, device, sm));
+            static const bool bits_on = lab_env_int("FOSVOS_RELU_BITS", 1) != 0;  // lab switch: 0 = read conv1_1's output itself
+            if (c == 1 && bits_on)  // conv1_2: its input's ReLU mask as the bits conv1_1's forward wrote (8 B instead of 128 B a pixel)
+                FOSVOS_TRY(fosvos_conv3x3_dgrad_bits(gact(c), w->conv_wd[c], reinterpret_cast<const uint8_t *>(base + a.bits0), nullptr,
+                                                     dx, N, hh, ww, kCin[c], kCout[c], ws, a.ws_bytes, device, sm));
+            else
+                FOSVOS_TRY(fosvos_conv3x3_dgrad(gact(c), w->conv_wd[c], mask, nullptr, dx, N, hh, ww, kCin[c], kCout[c], ws,
+                                                a.ws_bytes, device, sm));
             const bool skip_event = (last - first == 2) && c == last;  // gact(last-1): covered by the middle conv's event
             if (!from_pool && !skip_event) FOSVOS_TRY(publish(c - 1));
             if (middle)

@@ -190,7 +190,9 @@ def pack_conv3x3_weights_multi(ws: Sequence[torch.Tensor]):
 
 
 # ------------------------------------------------------------------------------------------ conv
-def conv3x3_first_fwd(frame: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+def conv3x3_first_fwd(frame: torch.Tensor, w: torch.Tensor, b: torch.Tensor, want_bits: bool = False):
+    """y bf16 NHWC; want_bits: (y, relu_bits) with relu_bits uint8 [N,H,W,Co/8], bit e of byte g = (y[..., 8 g + e] > 0)
+    (fosvos_conv3x3_first_fwd_bits: what conv3x3_dgrad takes as ``relu_bits``)."""
     _need(frame, _F32, "conv3x3_first_fwd frame"); _need(w, _F32, "conv3x3_first_fwd weight"); _need(b, _F32, "conv3x3_first_fwd bias")
     n, c, h, wd = frame.shape
     if c != 3 or tuple(w.shape[1:]) != (3, 3, 3):
@@ -199,10 +201,11 @@ def conv3x3_first_fwd(frame: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> 
     y = torch.empty((n, h, wd, co), dtype=_BF16, device=frame.device)
     dev, st = _ctx(frame)
     t0 = _pb()
-    check(lib().fosvos_conv3x3_first_fwd(frame.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), n, h, wd, co, dev, st),
-          "conv3x3_first_fwd")
+    bits = torch.empty((n, h, wd, co // 8), dtype=torch.uint8, device=frame.device) if want_bits else None
+    check(lib().fosvos_conv3x3_first_fwd_bits(frame.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), _p(bits), n, h, wd, co,
+                                              dev, st), "conv3x3_first_fwd")
     _pe(t0, "conv1_1_fwd", 2.0 * n * h * wd * 27 * co, n * h * wd * (12 + 2 * co))
-    return y
+    return (y, bits) if want_bits else y
 
 
 def conv3x3_first_wgrad(frame: torch.Tensor, dy: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -303,8 +306,9 @@ def conv3x3_fwd_pool(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[tor
 
 def conv3x3_dgrad(dy: torch.Tensor, w_dgrad_packed: torch.Tensor, ci: int, co: int,
                   relu_src: Optional[torch.Tensor] = None, addend: Optional[torch.Tensor] = None,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dx[N,H,W,Ci] = mask_{relu_src>0}(dgrad(dy)) + addend.  ``out`` may alias ``addend``."""
+                  out: Optional[torch.Tensor] = None, relu_bits: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx[N,H,W,Ci] = mask_{relu_src>0}(dgrad(dy)) + addend.  ``out`` may alias ``addend``.  ``relu_bits`` (uint8
+    [N,H,W,Ci/8], instead of ``relu_src``): the same mask as one bit per element (fosvos_conv3x3_dgrad_bits)."""
     _need(dy, _BF16, "conv3x3_dgrad dy"); _need(w_dgrad_packed, _BF16, "conv3x3_dgrad packed weight")
     n, h, wd, cy = dy.shape
     if cy != _ru(co, 32):
@@ -322,8 +326,15 @@ def conv3x3_dgrad(dy: torch.Tensor, w_dgrad_packed: torch.Tensor, ci: int, co: i
     ws, wsn = _WS.get(L.fosvos_conv3x3_workspace_bytes(n, h, wd, co, ci), dy.device)
     dev, st = _ctx(dy)
     t0 = _pb()
-    check(L.fosvos_conv3x3_dgrad(dy.data_ptr(), w_dgrad_packed.data_ptr(), _p(relu_src), _p(addend), dx.data_ptr(), n, h, wd,
-                                 ci, co, ws, wsn, dev, st), "conv3x3_dgrad")
+    if relu_bits is not None:
+        if relu_src is not None or relu_bits.dtype != torch.uint8 or tuple(relu_bits.shape) != (n, h, wd, ci // 8) or \
+                not relu_bits.is_contiguous() or not relu_bits.is_cuda:
+            raise ValueError("conv3x3_dgrad: relu_bits must be a contiguous uint8 [N,H,W,Ci/8] GPU tensor, given instead of relu_src")
+        check(L.fosvos_conv3x3_dgrad_bits(dy.data_ptr(), w_dgrad_packed.data_ptr(), relu_bits.data_ptr(), _p(addend),
+                                          dx.data_ptr(), n, h, wd, ci, co, ws, wsn, dev, st), "conv3x3_dgrad_bits")
+    else:
+        check(L.fosvos_conv3x3_dgrad(dy.data_ptr(), w_dgrad_packed.data_ptr(), _p(relu_src), _p(addend), dx.data_ptr(), n, h, wd,
+                                     ci, co, ws, wsn, dev, st), "conv3x3_dgrad")
     _pe(t0, "conv3x3_dgrad", 2.0 * n * h * wd * 9 * ci * co,
         n * h * wd * 2 * (cy + ci * (1 + (relu_src is not None) + (addend is not None))) + 2 * 9 * ci * co)
     return dx

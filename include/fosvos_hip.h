@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 15
+#define FOSVOS_ABI_VERSION 16
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -124,6 +124,10 @@ int fosvos_pack_conv3x3_weights_multi(const fosvos_pack_entry *entries, int n, i
  * replaces: stages[0][0..1] = Conv2d(3,64,3,pad=1)+ReLU (src/networks/osvos_vgg.py:92-93). */
 int fosvos_conv3x3_first_fwd(const float *frame, const float *w_oihw, const float *bias, uint16_t *y, int N, int H,
                              int W, int Co, int device, void *stream);
+/* The same, also writing the ReLU mask of y as one bit per element: relu_bits [N,H,W,Co/8] bytes (NULL = none), bit e of
+ * byte g set where y[..., 8 g + e] > 0 - what fosvos_conv3x3_dgrad_bits reads instead of y. */
+int fosvos_conv3x3_first_fwd_bits(const float *frame, const float *w_oihw, const float *bias, uint16_t *y,
+                                  uint8_t *relu_bits, int N, int H, int W, int Co, int device, void *stream);
 /* Launch geometry of the above: 8 x 32-pixel tiles and the (persistent) workgroups that walk them; tiles > workgroups
  * means every workgroup loops over several tiles with its double-buffered staging.  Host arithmetic only. */
 int fosvos_conv3x3_first_plan(int N, int H, int W, int *tiles, int *workgroups);
@@ -195,6 +199,13 @@ int fosvos_conv3x3_fwd_plan(int N, int H, int W, int in_ch, int out_ch, unsigned
 int fosvos_conv3x3_dgrad(const uint16_t *dy, const uint16_t *w_dgrad_packed, const uint16_t *relu_src,
                          const uint16_t *addend, uint16_t *dx, int N, int H, int W, int Ci, int Co, void *workspace,
                          size_t workspace_bytes, int device, void *stream);
+/* The same with the ReLU mask given as ONE BIT per element: relu_bits [N,H,W,Ci/8] bytes, bit e of byte g set where channel
+ * 8 g + e of the producing layer's output is > 0 (fosvos_conv3x3_first_fwd_bits writes it for conv1_1).  Bit for bit the
+ * result of fosvos_conv3x3_dgrad on the bf16 image the bits were taken from; 1/16 of the mask bytes - conv1_2's data gradient
+ * at 480x854 is bound by HBM traffic. */
+int fosvos_conv3x3_dgrad_bits(const uint16_t *dy, const uint16_t *w_dgrad_packed, const uint8_t *relu_bits,
+                              const uint16_t *addend, uint16_t *dx, int N, int H, int W, int Ci, int Co, void *workspace,
+                              size_t workspace_bytes, int device, void *stream);
 /* dw[Co,Ci,3,3] (fp32 OIHW) and db[Co] (may be NULL) from x[N,H,W,Ci] and dy[N,H,W,Co_pad] (bf16).
  * Deterministic: split partial sums are written as slabs to the workspace and reduced in a fixed
  * order.  accumulate != 0 adds into dw/db instead of overwriting.

@@ -582,6 +582,38 @@ def _head_ref(side, up, up1, dsn_w, dsn_b, fuse_w, fuse_b, H, W):
     return outs + [fused]
 
 
+@pytest.mark.parametrize("n,h,w,co", [(1, 48, 86, 64), (2, 61, 107, 128), (1, 30, 54, 512), (3, 480, 854, 64)])
+def test_relu_mask_as_bits(ops, n, h, w, co):
+    """conv1_1's forward can write the ReLU mask of its output as one bit per element (fosvos_conv3x3_first_fwd_bits), and the
+    data gradient of the next conv can take its mask that way (fosvos_conv3x3_dgrad_bits: 8 instead of 128 bytes per pixel at
+    64 channels - conv1_2's data gradient at 480x854 is bound by HBM traffic): the bits ARE (y > 0), and the data gradient is
+    bit for bit the one computed from y itself - in the fused epilogue and in the split-K epilogue (the small shapes)."""
+    g = torch.Generator().manual_seed(400 + h)
+    if co == 64:
+        frame = torch.randn(n, 3, h, w, generator=g).to(DEV)
+        w1 = (torch.randn(64, 3, 3, 3, generator=g) * 0.3).to(DEV)
+        b1 = (torch.randn(64, generator=g) * 0.5).to(DEV)
+        y, bits = ops.conv3x3_first_fwd(frame, w1, b1, want_bits=True)
+        assert torch.equal(y, ops.conv3x3_first_fwd(frame, w1, b1))
+    else:  # any other producer: the bits are taken on the host here
+        y = torch.relu(torch.randn(n, h, w, co, generator=g)).to(torch.bfloat16).to(DEV)
+        bits = None
+    pos = (y.float() > 0).reshape(n, h, w, co // 8, 8).to(torch.uint8)
+    want_bits = (pos * (2 ** torch.arange(8, device=DEV, dtype=torch.uint8))).sum(-1).to(torch.uint8)
+    if bits is not None:
+        assert torch.equal(bits, want_bits) and 0.2 < pos.float().mean().item() < 0.8
+    bits = want_bits.contiguous()
+    cout = 64
+    wt = torch.randn(cout, co, 3, 3, generator=g) * 0.05
+    _, wd = ops.pack_conv3x3_weights(wt.to(DEV))
+    dy = torch.randn(n, h, w, cout, generator=g).to(torch.bfloat16).to(DEV)
+    add = torch.randn(n, h, w, co, generator=g).to(torch.bfloat16).to(DEV)
+    for addend in (None, add):
+        a = ops.conv3x3_dgrad(dy, wd, co, cout, relu_src=y, addend=addend)
+        b = ops.conv3x3_dgrad(dy, wd, co, cout, relu_bits=bits, addend=addend)
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("n,H,W,uniform", [(1, 48, 86, 0b1111), (2, 61, 107, 0b0101), (1, 33, 47, 0b1010), (3, 17, 16, 0b1000)])
 def test_head_channel_uniform_filters(ops, n, H, W, uniform):
     """filt_uniform: where a scale's 16 channel filters are identical (what interp_surgery writes and lr 0 keeps,
