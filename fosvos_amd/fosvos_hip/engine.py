@@ -394,6 +394,7 @@ class ArenaPool:
         # arenas (and the frames of their passes: conv1_1's weight gradient reads the frame itself) that deferred
         # weight-gradient kernels on the auxiliary stream may still read
         self._pending: List[Tuple[int, int, int, torch.Tensor, Optional[torch.Tensor]]] = []
+        self._home: Dict[int, Tuple[int, int, int, int]] = {}  # arena address -> the key it was allocated for
 
     def aux_stream(self, device_index: int) -> int:
         """Handle of the auxiliary HIP stream the backward pass issues its weight-gradient kernels on
@@ -413,12 +414,22 @@ class ArenaPool:
         return c.handle
 
     def take(self, n: int, h: int, w: int, device: torch.device) -> torch.Tensor:
-        key = (n, h, w, device.index if device.index is not None else torch.cuda.current_device())
+        dev = device.index if device.index is not None else torch.cuda.current_device()
+        key = (n, h, w, dev)
         free = self._free.setdefault(key, [])
         if free:
             return free.pop()
+        # a free arena of a LARGER batch at the same frame size serves as well (the layout is computed from the pass's own N
+        # and only has to fit): a loop whose groups vary in size - frames of several shapes, bucketed per cycle - then
+        # allocates per frame size, not per (group size, frame size), and no multi-gigabyte hipMalloc lands in a later cycle
         nbytes = lib().fosvos_vgg_arena_bytes(n, h, w)
-        return torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        for (n2, h2, w2, d2), lst in self._free.items():
+            # (an arena's size is not monotonic in N: fewer frames can mean more K splits and a larger workspace)
+            if lst and h2 == h and w2 == w and d2 == dev and n2 > n and lst[-1].numel() >= nbytes + 256:
+                return lst.pop()
+        arena = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        self._home[arena.data_ptr()] = key
+        return arena
 
     def hold(self, n: int, h: int, w: int, arena: torch.Tensor, frame: Optional[torch.Tensor] = None) -> None:
         self._pending.append((n, h, w, arena, frame))
@@ -432,10 +443,12 @@ class ArenaPool:
         self._pending.clear()
 
     def give(self, n: int, h: int, w: int, arena: torch.Tensor) -> None:
-        key = (n, h, w, arena.device.index)
+        key = self._home.get(arena.data_ptr(), (n, h, w, arena.device.index))  # (back to the size it was allocated for)
         free = self._free.setdefault(key, [])
         if len(free) < 6:  # (a cycle of single-frame passes holds one arena per pass until its join)
             free.append(arena)
+        else:
+            self._home.pop(arena.data_ptr(), None)
 
 
 def _aligned_ptr(arena: torch.Tensor) -> Tuple[int, int]:
