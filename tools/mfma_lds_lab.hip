@@ -242,8 +242,8 @@ __device__ __forceinline__ void lab_dma16(const __amdgpu_buffer_rsrc_t rsrc, uns
 }
 #pragma clang diagnostic pop
 
-template <int MEM, int ND, int NS, bool SHARED_SRC = false>
-__global__ __launch_bounds__(MEM == 2 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(MEM == 2 ? 2 : 1, MEM == 2 ? 2 : 1)))
+template <int MEM, int ND, int NS, bool SHARED_SRC = false, int WGS = 1>
+__global__ __launch_bounds__(MEM == 2 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(MEM == 2 ? 2 : WGS, MEM == 2 ? 2 : WGS)))
 void k_mem(float *out, const uint4 *src, uint4 *dst, int chunks) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     constexpr int MF = 4, NF = 4, TW = 32, HALO_W = TW + 2, NPIX_PAD = ((4 * MF * 16 / TW + 2) * HALO_W + 3 + 15) / 16 * 16, BN = 16 * NF;
@@ -331,19 +331,19 @@ void k_mem(float *out, const uint4 *src, uint4 *dst, int chunks) {
     }
 }
 
-template <int MEM, int ND, int NS, bool SHARED_SRC = false>
+template <int MEM, int ND, int NS, bool SHARED_SRC = false, int WGS = 1>
 void run_mem(const char *name, float *out, const uint4 *src, uint4 *dst, int chunks = 1024) {
-    const int grid = 256, lds = 150 * 1024;  // one workgroup per CU
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mem<MEM, ND, NS, SHARED_SRC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int grid = 256 * WGS, lds = 150 * 1024 / WGS;  // WGS workgroups per CU (by their LDS request)
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mem<MEM, ND, NS, SHARED_SRC, WGS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const int threads = MEM == 2 ? 512 : 256;
-    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_mem<MEM, ND, NS, SHARED_SRC>), dim3(grid), dim3(threads), lds, 0, out, src, dst, chunks);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_mem<MEM, ND, NS, SHARED_SRC, WGS>), dim3(grid), dim3(threads), lds, 0, out, src, dst, chunks);
     CK(hipDeviceSynchronize());
     const int reps = 20;
     CK(hipEventRecord(e0));
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_mem<MEM, ND, NS, SHARED_SRC>), dim3(grid), dim3(threads), lds, 0, out, src, dst, chunks);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_mem<MEM, ND, NS, SHARED_SRC, WGS>), dim3(grid), dim3(threads), lds, 0, out, src, dst, chunks);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -393,9 +393,9 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&out, 64 << 20));
     if (argc > 1 && !strcmp(argv[1], "mem")) {
         uint4 *src, *dst;
-        CK(hipMalloc(&src, 256u * 4 * 65536));
-        CK(hipMalloc(&dst, 256u * 4 * 65536));
-        CK(hipMemset(src, 1, 256u * 4 * 65536));
+        CK(hipMalloc(&src, 512u * 4 * 65536));
+        CK(hipMalloc(&dst, 512u * 4 * 65536));
+        CK(hipMemset(src, 1, 512u * 4 * 65536));
         run_mem<0, 10, 6>("no memory instructions (1 wave / SIMD)", out, src, dst);
         run_mem<1, 10, 6>("MFMA waves issue them (as the conv kernels)", out, src, dst);
         run_mem<2, 10, 6>("four producer waves issue them", out, src, dst);
@@ -405,6 +405,10 @@ int main(int argc, char **argv) {
         run_mem<2, 10, 0, true>("producer waves: loads only, L2-resident", out, src, dst);
         run_mem<1, 10, 3, true>("MFMA waves: L2 loads + 3 stores", out, src, dst);
         run_mem<2, 10, 3, true>("producer waves: L2 loads + 3 stores", out, src, dst);
+        run_mem<0, 10, 3, true, 2>("2 workgroups / CU: no memory instructions", out, src, dst);
+        run_mem<1, 10, 0, true, 2>("2 workgroups / CU: MFMA waves, L2 loads", out, src, dst);
+        run_mem<1, 10, 3, true, 2>("2 workgroups / CU: MFMA waves, L2 loads + 3 stores", out, src, dst);
+        run_mem<1, 10, 6, true, 2>("2 workgroups / CU: MFMA waves, L2 loads + 6 stores", out, src, dst);
         run_mem<1, 10, 0>("MFMA waves: loads only", out, src, dst);
         run_mem<1, 0, 6>("MFMA waves: stores only", out, src, dst);
         return 0;
