@@ -202,6 +202,10 @@ def lib() -> ctypes.CDLL:
             raise FosvosHipError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"or `make -C fosvos_amd/csrc`.  There is no CPU fallback.")
+        # torch first: its HIP runtime must be the one in the process when the library's own dependency on libamdhip64 is
+        # resolved (loaded the other way round - the library before torch, as a build()-then-smoke() process did - the
+        # library's calls ran on a second runtime that found no device: "no ROCm-capable device is detected")
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing
