@@ -138,7 +138,8 @@ inline int lab_env_int(const char *name, int dflt) {
 bool conv_pp_applicable(int N, int H, int W, int in_ch, int out_ch);
 int conv_pp_workgroups();
 int conv_pp_forward(const uint16_t *x, const uint16_t *w_packed, const float *bias, uint16_t *y, uint16_t *y_pool, int N,
-                    int H, int W, int Cin_pad, int Cout, int Co_pad, bool relu, hipStream_t st);
+                    int H, int W, int Cin_pad, int Cout, int Co_pad, bool relu, hipStream_t st,
+                    const uint8_t *mask_bits = nullptr);
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int roundup(int a, int b) { return (a + b - 1) / b * b; }

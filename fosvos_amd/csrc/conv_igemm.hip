@@ -940,6 +940,12 @@ extern "C" int fosvos_conv3x3_dgrad_bits(const uint16_t *dy, const uint16_t *w_d
     if (int rc = check_common(dy, w_dgrad_packed, dx, N, H, W, Co, Ci, "conv3x3_dgrad_bits")) return rc;
     FOSVOS_REQUIRE(relu_bits && Ci % 8 == 0, FOSVOS_E_ARG, "conv3x3_dgrad_bits: null mask or Ci=%d not a multiple of 8", Ci);
     FOSVOS_ENTER(device);
+    // the persistent kernel (conv_pp.hip) where the forward pass takes it too - as a data gradient it is the same conv on the
+    // rotated filter image, its epilogue the bit mask (lab switch FOSVOS_PP_DGRAD=0: the igemm)
+    if (!addend && lab_env_int("FOSVOS_PP_DGRAD", 1) != 0 && lab_env_int("FOSVOS_PP", -1) != 0 &&
+        conv_pp_applicable(N, H, W, roundup(Co, 32), Ci))
+        return conv_pp_forward(dy, w_dgrad_packed, nullptr, dx, nullptr, N, H, W, roundup(Co, 32), Ci, roundup(Ci, 16), false,
+                               (hipStream_t)stream, relu_bits);
     ConvArgs a{};
     a.x = dy; a.w = w_dgrad_packed; a.bias = nullptr; a.relu_src = nullptr; a.relu_bits = relu_bits; a.addend = addend; a.y = dx;
     a.N = N; a.H = H; a.W = W; a.Cin = roundup(Co, 32); a.Cout = Ci; a.Co_pad = roundup(Ci, 16); a.flags = 0;

@@ -65,6 +65,7 @@ struct Args {
     const float *bias;   // [Cout] or null
     uint16_t *y;         // [N,H,W,Cout] bf16
     uint16_t *y_pool;    // optional [N,ceil(H/2),ceil(W/2),Cout]
+    const uint8_t *mask_bits;  // MASK: [N,H,W,Cout/8] bytes, bit e of byte g set = keep channel 8 g + e (a data gradient's ReLU mask)
     int N, H, W, Cin, Cout, Co_pad;
     int tiles_x, tiles_y, n_tiles;  // pixel tiles per row / per image / of the launch
     int n_cb;                       // 64-channel blocks
@@ -140,7 +141,7 @@ struct TileIt {
     __device__ __forceinline__ int x0() const { return tx * TW; }
 };
 
-template <bool RELU, bool POOL>
+template <bool RELU, bool POOL, bool MASK = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv3x3_pp(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem_pp[];
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void *)smem_pp);
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // instructions at a time between the taps (a burst of twelve stores would hold this wave - and, the groups running in
     // lockstep, its SIMD partner too - for thousands of clocks with no MFMA issued)
     uint4 pk[4][2];
+    unsigned mb[MASK ? 4 : 1][2];  // MASK: the mask bytes of the packed vectors, requested when the tile is packed
     int dn_n = 0, dn_y0 = 0, dn_x0 = 0;  // the tile they belong to
     int st_pending = 0;
     auto pack_frag = [&](int i, int jp) {
@@ -308,6 +310,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             pk[i][0] = pack_frag(i, 0);
             pk[i][1] = pack_frag(i, 1);
         }
+        if constexpr (MASK) {  // one byte per 16-byte vector; they have the next super-step's first taps to arrive under
+            const auto m_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.mask_bits) + (int64_t)dn_n * H * W * (Cout >> 3),
+                                                                  0, H * W * (Cout >> 3), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gy = dn_y0 + 2 * wm + (i >> 1), gx = dn_x0 + (i & 1) * 16 + cl;
+                const unsigned off = (gy < H && gx < W) ? (unsigned)((gy * W + gx) * (Cout >> 3) + (n0 >> 3) + kq) : 0x80000000u;
+                mb[i][0] = __builtin_amdgcn_raw_buffer_load_b8(m_rsrc, off, 0, 0);
+                mb[i][1] = __builtin_amdgcn_raw_buffer_load_b8(m_rsrc, off + 4, 0, 0);
+            }
+        }
+    };
+    auto mask_bits_of = [](unsigned b) {  // eight bits -> the 0 / 1 halfwords keep_where_pos_bf16x8 tests
+        return make_uint4((b & 1u) | ((b & 2u) << 15), ((b >> 2) & 1u) | ((b & 8u) << 13), ((b >> 4) & 1u) | ((b & 32u) << 11),
+                          ((b >> 6) & 1u) | ((b & 128u) << 9));
     };
     // slot 0..3: fragment i's two 16-byte stores; slots 4, 5 (POOL): the pooled vectors of column half ih = slot - 4
     auto store_slot = [&](int slot) {
@@ -316,8 +333,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + (int64_t)dn_n * H * W * Cout, 0, H * W * Cout * 2, 0x00020000);
             const int gy = dn_y0 + 2 * wm + (slot >> 1), gx = dn_x0 + (slot & 1) * 16 + cl;
             const unsigned off = (gy < H && gx < W) ? (unsigned)(((gy * W + gx) * Cout + n0 + kq * 8) * 2) : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk[slot][0]), y_rsrc, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk[slot][1]), y_rsrc, off + 64, 0, 0);
+            uint4 v0 = pk[slot][0], v1 = pk[slot][1];
+            if constexpr (MASK) {
+                v0 = keep_where_pos_bf16x8(v0, mask_bits_of(mb[slot][0]));
+                v1 = keep_where_pos_bf16x8(v1, mask_bits_of(mb[slot][1]));
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), y_rsrc, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), y_rsrc, off + 64, 0, 0);
         } else if constexpr (POOL) {
             // MaxPool2d(2, 2, ceil_mode=True) of the tile (its origin is even, so no window straddles two tiles): rows 2 wm and
             // 2 wm + 1 are fragments ih and ih + 2 of the SAME lane, columns 2 c and 2 c + 1 are neighbouring lanes.  Post-ReLU
@@ -472,10 +494,11 @@ bool conv_pp_applicable(int N, int H, int W, int in_ch, int out_ch) {
 
 
 int conv_pp_forward(const uint16_t *x, const uint16_t *w_packed, const float *bias, uint16_t *y, uint16_t *y_pool, int N,
-                    int H, int W, int Cin_pad, int Cout, int Co_pad, bool relu, hipStream_t st) {
+                    int H, int W, int Cin_pad, int Cout, int Co_pad, bool relu, hipStream_t st, const uint8_t *mask_bits) {
     FOSVOS_REQUIRE(!y_pool || relu, FOSVOS_E_ARG, "conv3x3 (persistent): the fused pool takes post-ReLU values");
+    FOSVOS_REQUIRE(!mask_bits || (!relu && !y_pool && !bias), FOSVOS_E_ARG, "conv3x3 (persistent): the bit mask is the data gradient's epilogue");
     pp::Args a{};
-    a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.y_pool = y_pool;
+    a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.y_pool = y_pool; a.mask_bits = mask_bits;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin_pad; a.Cout = Cout; a.Co_pad = Co_pad;
     a.tiles_x = (int)cdiv(W, pp::TW);
     a.tiles_y = (int)cdiv(H, pp::TH);
@@ -485,10 +508,11 @@ int conv_pp_forward(const uint16_t *x, const uint16_t *w_packed, const float *bi
 #ifdef FOSVOS_LAB_BUILD
     a.stamps = g_pp_stamps;
 #endif
-    void (*kern)(const pp::Args) = y_pool ? pp::k_conv3x3_pp<true, true>
-                                   : relu ? pp::k_conv3x3_pp<true, false> : pp::k_conv3x3_pp<false, false>;
-    const int which = y_pool ? 2 : relu ? 1 : 0;
-    static bool once[64][3];
+    void (*kern)(const pp::Args) = mask_bits ? pp::k_conv3x3_pp<false, false, true>
+                                   : y_pool  ? pp::k_conv3x3_pp<true, true>
+                                   : relu    ? pp::k_conv3x3_pp<true, false> : pp::k_conv3x3_pp<false, false>;
+    const int which = mask_bits ? 3 : y_pool ? 2 : relu ? 1 : 0;
+    static bool once[64][4];
     int dev = 0;
     FOSVOS_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !once[dev][which]) {  // opt in to the whole LDS of a CU, once per device and instantiation
@@ -496,7 +520,8 @@ int conv_pp_forward(const uint16_t *x, const uint16_t *w_packed, const float *bi
                                              pp::LDS_BYTES));
         once[dev][which] = true;
     }
-    FOSVOS_PROF(y_pool ? "k_conv3x3_pp<true, true>" : relu ? "k_conv3x3_pp<true, false>" : "k_conv3x3_pp<false, false>", st,
+    FOSVOS_PROF(mask_bits ? "k_conv3x3_pp<false, false, true>" : y_pool ? "k_conv3x3_pp<true, true>"
+                : relu    ? "k_conv3x3_pp<true, false>" : "k_conv3x3_pp<false, false>", st,
                 2.0 * N * H * W * 9.0 * Cin_pad * Cout);
     hipLaunchKernelGGL(kern, dim3(conv_pp_workgroups()), dim3(pp::NT), pp::LDS_BYTES, st, a);
     FOSVOS_LAUNCH_CHECK();
