@@ -691,6 +691,26 @@ def test_shipped_offline_train_vs_golden(golden):
     print(f"[offline] worst delta rel-L2 {worst[1]:.3e} at {worst[0]}")
 
 
+def test_arena_pool_reuses_larger_free_arenas():
+    """A pass of fewer frames takes a free arena of a larger batch at the same frame size when that arena is large enough (an
+    arena's size is not monotonic in N), and the arena goes back to the size it was allocated for."""
+    from fosvos_hip import engine, lib
+    pool = engine.ArenaPool()
+    dev = torch.device(DEV)
+    big = pool.take(5, 40, 70, dev)
+    need3 = lib().fosvos_vgg_arena_bytes(3, 40, 70)
+    pool.give(5, 40, 70, big)
+    got = pool.take(3, 40, 70, dev)
+    if big.numel() >= need3 + 256:
+        assert got.data_ptr() == big.data_ptr()
+        pool.give(3, 40, 70, got)                         # ... returns to the five-frame list
+        assert pool.take(5, 40, 70, dev).data_ptr() == big.data_ptr()
+    else:
+        assert got.data_ptr() != big.data_ptr() and got.numel() >= need3
+    other = pool.take(3, 32, 56, dev)                      # another frame size: its own arena
+    assert other.data_ptr() != big.data_ptr()
+
+
 def test_native_loop_equals_per_op_engine():
     """The native layer loop (csrc/vgg_net.hip, what ships) and the per-op Python engine (what per-kernel event timing
     brackets) issue the same kernels with the same per-frame arithmetic: logits and every gradient bit for bit.  (The native
