@@ -43,6 +43,7 @@ struct ConvArgs {
     const uint16_t *addend;    // [N,H,W,Cout] or null
     void *y;                   // [N,H,W,Cout] bf16 (or fp32)
     uint16_t *y_pool;          // optional [N,ceil(H/2),ceil(W/2),Cout] bf16: 2x2 ceil-mode max pool of y, same launch
+    const uint16_t *unpool_g;  // UNPOOL kernels: [N,ceil(H/2),ceil(W/2),Cout] bf16, the gradient wrt the 2x2 max pool of relu_src
     int N, H, W, Cin, Cout, Co_pad;
     int tiles_x, tiles_y;
     unsigned flags;
@@ -145,7 +146,10 @@ __device__ __forceinline__ void sched_tap() {
 
 // waves_per_eu(2,2): two workgroups per CU, up to 256 registers each - without the cap hipcc spills the
 // prefetched chunk to scratch to reach an occupancy the LDS image would not allow anyway
-template <class T, bool OUT_F32>
+// UNPOOL (the side_prep data gradient of the training step): y = [relu_src > 0] * conv + maxpool2x2_ceil_bwd(relu_src, unpool_g) -
+// the pool backward of the stage output runs in THIS epilogue instead of as its own pass whose result would be read back as
+// the addend (per stage output of P pooled bytes: 9 P of pool pass + 12 P here become 9 P).  See the epilogue.
+template <class T, bool OUT_F32, bool UNPOOL = false>
 __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE))) void k_conv3x3_igemm(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     uint4 *sA = smem;
@@ -401,7 +405,23 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
     uint4 mk[OUT_IT], ad[OUT_IT];
 #pragma unroll
     for (int it = 0; it < OUT_IT; ++it) mk[it] = ad[it] = make_uint4(0, 0, 0, 0);
-    if (masked && a.relu_bits) {
+    if constexpr (UNPOOL) {
+        // own pixel of the pooled map's input (it is also the ReLU mask) and the pooled gradient of its window
+        const int OH = (H + 1) >> 1, OW = (W + 1) >> 1;
+        auto m_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.relu_src + (int64_t)n * H * W * a.Cout), 0,
+                                                        img_bytes, 0x00020000);
+        auto g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(a.unpool_g + (int64_t)n * OH * OW * a.Cout), 0,
+                                                        OH * OW * a.Cout * 2, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < OUT_IT; ++it)
+            mk[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(m_rsrc, voff[it], 0, 0));
+#pragma unroll
+        for (int it = 0; it < OUT_IT; ++it) {
+            const int gy = y0 + o_ly + it * ROW_STEP;
+            const int goff = voff[it] < 0 ? -1 : (((gy >> 1) * OW + (o_gx >> 1)) * a.Cout + n0 + o_cg * 8) * 2;
+            ad[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, goff, 0, 0));
+        }
+    } else if (masked && a.relu_bits) {
         // the ReLU mask as bits: one byte per 16-byte vector of the bf16 image, expanded to the 0 / 1 halfwords that
         // keep_where_pos_bf16x8 tests (an HBM-bound data gradient - conv1_2's - reads 8 instead of 128 bytes per pixel)
         auto b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.relu_bits + (int64_t)n * H * W * (a.Cout >> 3)), 0,
@@ -454,11 +474,54 @@ __global__ __launch_bounds__(T::NT) __attribute__((amdgpu_waves_per_eu(2, T::WPE
             *reinterpret_cast<uint2 *>(sO + pix * T::OUT_LD + col) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
         }
     }
+    if constexpr (UNPOOL) {  // the tile of relu_src next to the output tile (out-of-image pixels: zeros, by the range check)
+        uint16_t *sX = sO + T::BM * T::OUT_LD;
+#pragma unroll
+        for (int it = 0; it < OUT_IT; ++it)
+            if (it * T::NT + tid < OUT_N)
+                *reinterpret_cast<uint4 *>(sX + (o_pix + it * PIX_STEP) * T::OUT_LD + o_cg * 8) = mk[it];
+    }
     __syncthreads();
     FOSVOS_STAMP_AT(9)
     const uint16_t *s_vec = sO + o_pix * T::OUT_LD + o_cg * 8;  // this thread's first staged vector; the next is PIX_STEP rows of sO on
     auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc(yo + (int64_t)n * H * W * a.Cout, 0, img_bytes, 0x00020000);
-    if (!(a.flags & kSubsample2)) {
+    if constexpr (UNPOOL) {
+        // MaxPool2d(2, 2, ceil_mode=True) backward of this tile (its origin and sizes are even: no window straddles two tiles).
+        // A pixel at position t = 2 (row & 1) + (column & 1) of its window takes the window's gradient where it is the FIRST
+        // maximum in scan order and > 0 (k_pool_bwd's rule, its ReLU mask included): own > x for the earlier positions, own >=
+        // x for the later ones.  The values are post-ReLU bf16 - they order like 16-bit integers below 0x8000 - so
+        // "own > x" is the sign of x - own and "own >= x" the sign of x - own - 1, two elements per v_pk_sub_i16; missing
+        // window pixels (ragged last row / column) are zeros in sX and never beat a positive own.
+        static_assert((T::TW & (T::TW - 1)) == 0 && T::TH % 2 == 0, "window partners are pix ^ 1 and pix ^ TW");
+        const uint16_t *sX = sO + T::BM * T::OUT_LD;
+        const fosvos_i16x2 one2 = {1, 1}, zero2 = {0, 0};
+        const fosvos_i16x2 late_x = (o_pix & 1) ? zero2 : one2;  // the column partner comes later in the scan
+#pragma unroll
+        for (int it = 0; it < OUT_IT; ++it) {
+            const int pix = o_pix + it * PIX_STEP;
+            if (it * T::NT + tid >= OUT_N) continue;
+            const fosvos_i16x2 late_y = (pix & T::TW) ? zero2 : one2;  // the partners in the other row (the diagonal one too)
+            const uint4 cv = keep_where_pos_bf16x8(*reinterpret_cast<const uint4 *>(s_vec + it * PIX_STEP * T::OUT_LD), mk[it]);
+            const uint4 x1 = *reinterpret_cast<const uint4 *>(sX + (pix ^ 1) * T::OUT_LD + o_cg * 8);
+            const uint4 x2 = *reinterpret_cast<const uint4 *>(sX + (pix ^ T::TW) * T::OUT_LD + o_cg * 8);
+            const uint4 x3 = *reinterpret_cast<const uint4 *>(sX + (pix ^ T::TW ^ 1) * T::OUT_LD + o_cg * 8);
+            auto win = [&](unsigned own_, unsigned p1, unsigned p2, unsigned p3) {
+                const fosvos_i16x2 own = __builtin_bit_cast(fosvos_i16x2, own_);
+                const fosvos_i16x2 s = (zero2 - own) & (__builtin_bit_cast(fosvos_i16x2, p1) - own - late_x) &
+                                       (__builtin_bit_cast(fosvos_i16x2, p2) - own - late_y) &
+                                       (__builtin_bit_cast(fosvos_i16x2, p3) - own - late_y);
+                return __builtin_bit_cast(unsigned, s >> 15);  // 0xffff where every sign is set
+            };
+            const uint4 routed = make_uint4(ad[it].x & win(mk[it].x, x1.x, x2.x, x3.x), ad[it].y & win(mk[it].y, x1.y, x2.y, x3.y),
+                                            ad[it].z & win(mk[it].z, x1.z, x2.z, x3.z), ad[it].w & win(mk[it].w, x1.w, x2.w, x3.w));
+            float f[8], r[8];
+            unpack8(cv, f);
+            unpack8(routed, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += r[e];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pack8(f)), y_rsrc, voff[it], 0, 0);
+        }
+    } else if (!(a.flags & kSubsample2)) {
         if (masked) {
 #pragma unroll
             for (int it = 0; it < OUT_IT; ++it) {
@@ -703,8 +766,10 @@ ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
     return p;
 }
 
-template <class T, bool OUT_F32>
+template <class T, bool OUT_F32, bool UNPOOL = false>
 int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st, int in_ch) {
+    // (UNPOOL: the tile of the pooled map's input sits behind the output tile)
+    constexpr int LDS = UNPOOL && 2 * T::LDS_OUT > T::LDS_MAIN ? 2 * T::LDS_OUT : T::LDS_BYTES;
     ConvArgs a = a0;
     a.tiles_x = (int)cdiv(a.W, T::TW);
     a.tiles_y = (int)cdiv(a.H, T::TH);
@@ -715,20 +780,20 @@ int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st, int in_ch) 
 #endif
     const int64_t tiles = (int64_t)a.tiles_x * a.tiles_y * a.N;
     FOSVOS_REQUIRE(tiles <= 0x7fffffff && a.Cout % T::BN == 0, FOSVOS_E_SHAPE, "conv3x3: tile grid");
-    if constexpr (T::LDS_BYTES > 64 * 1024) {  // opt in to more than 64 KB of dynamic LDS, once per device
+    if constexpr (LDS > 64 * 1024) {  // opt in to more than 64 KB of dynamic LDS, once per device
         static bool once[64];
         int dev = 0;
         FOSVOS_HIP_CHECK(hipGetDevice(&dev));
         if (dev >= 0 && dev < 64 && !once[dev]) {
-            FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_igemm<T, OUT_F32>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+            FOSVOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv3x3_igemm<T, OUT_F32, UNPOOL>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
             once[dev] = true;
         }
     }
     if (g_prof_on) {  // the name rocprofv3 prints for this instantiation
         static char name[80];
-        snprintf(name, sizeof(name), "k_conv3x3_igemm<Tile<%d, %d, %d, %d, %d>, %s>", T::TH, T::TW, T::BN, T::WM, T::WN,
-                 OUT_F32 ? "true" : "false");
+        snprintf(name, sizeof(name), "k_conv3x3_igemm<Tile<%d, %d, %d, %d, %d>, %s%s>", T::TH, T::TW, T::BN, T::WM, T::WN,
+                 OUT_F32 ? "true" : "false", UNPOOL ? ", true" : "");
         prof_begin(name, st, 2.0 * a.N * a.H * a.W * 9.0 * in_ch * a.Cout);
     }
     {
@@ -750,7 +815,7 @@ int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st, int in_ch) 
     }
     const dim3 grid = a.swizzle ? dim3((unsigned)(tiles * (a.Cout / T::BN)), 1u, (unsigned)plan.k_splits)
                                 : dim3((unsigned)tiles, (unsigned)(a.Cout / T::BN), (unsigned)plan.k_splits);
-    hipLaunchKernelGGL((k_conv3x3_igemm<T, OUT_F32>), grid, dim3(T::NT), T::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((k_conv3x3_igemm<T, OUT_F32, UNPOOL>), grid, dim3(T::NT), LDS, st, a);
     FOSVOS_LAUNCH_CHECK();
     if (plan.k_splits > 1) {
         const int64_t total8 = (a.flags & kSubsample2) ? (int64_t)a.N * ((a.H + 1) >> 1) * ((a.W + 1) >> 1) * (a.Cout / 8)
@@ -786,6 +851,14 @@ int dispatch(ConvArgs a, int in_ch, void *workspace, size_t workspace_bytes, hip
         FOSVOS_REQUIRE(workspace && workspace_bytes >= plan.workspace_bytes, FOSVOS_E_WORKSPACE,
                        "conv3x3: split-K needs %zu workspace bytes, got %zu", plan.workspace_bytes, workspace_bytes);
         a.partial = reinterpret_cast<float *>(workspace);
+    }
+    if (a.unpool_g) {  // (fosvos_conv3x3_dgrad_unpool has checked that the plan is one of these, unsplit)
+        switch (plan.tile) {
+            case kBig: return launch<TileBig, false, true>(a, plan, st, in_ch);
+            case kSquare: return launch<TileSquare, false, true>(a, plan, st, in_ch);
+            case kMid: return launch<TileMid, false, true>(a, plan, st, in_ch);
+            default: return fail(FOSVOS_E_ARG, "conv3x3: no fused pool backward for this tile");
+        }
     }
     switch (plan.tile) {
         case kBig: return launch<TileBig, false>(a, plan, st, in_ch);
@@ -948,6 +1021,25 @@ extern "C" int fosvos_conv3x3_dgrad_bits(const uint16_t *dy, const uint16_t *w_d
                                (hipStream_t)stream, relu_bits);
     ConvArgs a{};
     a.x = dy; a.w = w_dgrad_packed; a.bias = nullptr; a.relu_src = nullptr; a.relu_bits = relu_bits; a.addend = addend; a.y = dx;
+    a.N = N; a.H = H; a.W = W; a.Cin = roundup(Co, 32); a.Cout = Ci; a.Co_pad = roundup(Ci, 16); a.flags = 0;
+    return dispatch(a, Co, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int fosvos_conv3x3_dgrad_unpool(const uint16_t *dy, const uint16_t *w_dgrad_packed, const uint16_t *x,
+                                           const uint16_t *d_pooled, uint16_t *dx, int N, int H, int W, int Ci, int Co,
+                                           void *workspace, size_t workspace_bytes, int device, void *stream) {
+    if (int rc = check_common(dy, w_dgrad_packed, dx, N, H, W, Co, Ci, "conv3x3_dgrad_unpool")) return rc;
+    FOSVOS_REQUIRE(x && d_pooled && x != dx, FOSVOS_E_ARG, "conv3x3_dgrad_unpool: null or aliased pooled-map operands");
+    FOSVOS_ENTER(device);
+    const ConvPlan plan = make_plan(N, H, W, Co, Ci);
+    const bool fused = Ci % 64 == 0 && plan.k_splits == 1 && (plan.tile == kBig || plan.tile == kSquare || plan.tile == kMid) &&
+                       lab_env_int("FOSVOS_UNPOOL_FUSED", 1) != 0;  // lab switch: 0 = the two passes below
+    if (!fused) {  // the same sum as two passes: pool backward into dx, then the data gradient with dx as its addend
+        if (int rc = fosvos_maxpool2x2_ceil_bwd(x, d_pooled, dx, N, H, W, Ci, 1, device, stream)) return rc;
+        return fosvos_conv3x3_dgrad(dy, w_dgrad_packed, x, dx, dx, N, H, W, Ci, Co, workspace, workspace_bytes, device, stream);
+    }
+    ConvArgs a{};
+    a.x = dy; a.w = w_dgrad_packed; a.relu_src = x; a.unpool_g = d_pooled; a.y = dx;
     a.N = N; a.H = H; a.W = W; a.Cin = roundup(Co, 32); a.Cout = Ci; a.Co_pad = roundup(Ci, 16); a.flags = 0;
     return dispatch(a, Co, workspace, workspace_bytes, (hipStream_t)stream);
 }

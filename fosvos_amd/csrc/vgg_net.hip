@@ -364,6 +364,7 @@ extern "C" int fosvos_vgg_backward(fosvos_ctx *ctx, const fosvos_vgg_weights *w,
     FOSVOS_TRY(head_bwd_finish(ha, sa));
 
     // ---- stages 4..0
+    static const bool unpool_fused = lab_env_int("FOSVOS_UNPOOL", 1) != 0;  // lab switch: 0 = pool backward as its own pass
     for (int s = 4; s >= 0; --s) {
         const int hh = a.sh[s], ww = a.sw[s], last = kLastOfStage[s], first = kFirstOfStage[s];
         if (s > 0) {
@@ -374,8 +375,13 @@ extern "C" int fosvos_vgg_backward(fosvos_ctx *ctx, const fosvos_vgg_weights *w,
                                   (offload && s == 1) ? &reduce_m : &reduce, tail && s <= tail_stages));
             const uint16_t *addend = (s < 4) ? gact(last) : nullptr;
             if (par && s < 4) FOSVOS_HIP_CHECK(hipStreamWaitEvent(sm, ev[16 + s - 1], 0));  // d_side[s-1] from the wgrad stream
-            FOSVOS_TRY(fosvos_conv3x3_dgrad(dside[s - 1], w->side_wd[s - 1], act(last), addend, gact(last), N, hh, ww,
-                                            kStageCh[s], 16, ws, a.ws_bytes, device, sm));
+            if (s < 4 && unpool_fused)  // ... the pool backward in the same pass (no pool pass ran for this stage: see below)
+                FOSVOS_TRY(fosvos_conv3x3_dgrad_unpool(dside[s - 1], w->side_wd[s - 1], act(last),
+                                                       reinterpret_cast<const uint16_t *>(base + a.gpooled[s]), gact(last), N, hh,
+                                                       ww, kStageCh[s], 16, ws, a.ws_bytes, device, sm));
+            else
+                FOSVOS_TRY(fosvos_conv3x3_dgrad(dside[s - 1], w->side_wd[s - 1], act(last), addend, gact(last), N, hh, ww,
+                                                kStageCh[s], 16, ws, a.ws_bytes, device, sm));
         }
         FOSVOS_TRY(publish(last));  // gradient wrt the stage output is complete
         for (int c = last; c >= first; --c) {
@@ -415,7 +421,9 @@ extern "C" int fosvos_vgg_backward(fosvos_ctx *ctx, const fosvos_vgg_weights *w,
                                       base + a.wsa_conv[c], a.wsa_conv_bytes[c], device, sa,
                                       (offload && s == 1) ? &reduce_m : &reduce, tail && s <= tail_stages));
         }
-        if (s > 0)  // pool backward into the previous stage's output gradient, its ReLU mask fused
+        // pool backward into the previous stage's output gradient, its ReLU mask fused - for stage 1 only (it has no
+        // side_prep): the outputs of stages 2-4 get theirs inside side_prep's data gradient, next iteration
+        if (s == 1 || (s > 0 && !unpool_fused))
             FOSVOS_TRY(fosvos_maxpool2x2_ceil_bwd(act(kLastOfStage[s - 1]), reinterpret_cast<const uint16_t *>(base + a.gpooled[s - 1]),
                                                   gact(kLastOfStage[s - 1]), N, a.sh[s - 1], a.sw[s - 1], kStageCh[s - 1], 1,
                                                   device, sm));

@@ -17,7 +17,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # .../fosvos_amd
 LIB_PATH = os.environ.get("FOSVOS_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libfosvos_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_ROOT), "include", "fosvos_hip.h")
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 CONV_RELU = 1
 CONV_OUT_F32 = 2
 
@@ -110,6 +110,8 @@ SIGNATURES = {
                                               c_void_p]),
     "fosvos_conv3x3_dgrad_bits": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                           c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "fosvos_conv3x3_dgrad_unpool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                            c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "fosvos_conv3x3_first_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                            c_void_p, c_size_t, c_int, c_void_p]),
     "fosvos_conv3x3_first_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

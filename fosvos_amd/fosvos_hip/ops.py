@@ -340,6 +340,36 @@ def conv3x3_dgrad(dy: torch.Tensor, w_dgrad_packed: torch.Tensor, ci: int, co: i
     return dx
 
 
+def conv3x3_dgrad_unpool(dy: torch.Tensor, w_dgrad_packed: torch.Tensor, ci: int, co: int, x: torch.Tensor,
+                         d_pooled: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx[N,H,W,Ci] = [x > 0] * dgrad(dy) + maxpool2x2_ceil_bwd(x, d_pooled): the data gradient of a conv whose input ``x`` (a
+    post-ReLU stage output) also feeds the 2x2 ceil-mode max pool, the pool's backward in the same pass
+    (fosvos_conv3x3_dgrad_unpool; bit for bit ``conv3x3_dgrad(..., relu_src=x, addend=maxpool2x2_ceil_bwd(x, d_pooled))``)."""
+    _need(dy, _BF16, "conv3x3_dgrad_unpool dy"); _need(w_dgrad_packed, _BF16, "conv3x3_dgrad_unpool packed weight")
+    _need(x, _BF16, "conv3x3_dgrad_unpool x"); _need(d_pooled, _BF16, "conv3x3_dgrad_unpool d_pooled")
+    n, h, wd, cy = dy.shape
+    if cy != _ru(co, 32):
+        raise ValueError(f"conv3x3_dgrad_unpool: dy has {cy} channels, expected {_ru(co, 32)}")
+    L = lib()
+    if w_dgrad_packed.numel() != L.fosvos_packed_weight_elems(ci, co):
+        raise ValueError("conv3x3_dgrad_unpool: packed weight size does not match (Ci, Co)")
+    if tuple(x.shape) != (n, h, wd, ci) or tuple(d_pooled.shape) != (n, (h + 1) // 2, (wd + 1) // 2, ci):
+        raise ValueError(f"conv3x3_dgrad_unpool: x {tuple(x.shape)} / d_pooled {tuple(d_pooled.shape)} do not match "
+                         f"{(n, h, wd, ci)} and its ceil-mode pooled map")
+    if out is not None:
+        _need(out, _BF16, "conv3x3_dgrad_unpool out")
+        if tuple(out.shape) != (n, h, wd, ci) or out.data_ptr() == x.data_ptr():
+            raise ValueError("conv3x3_dgrad_unpool: out must have x's shape and must not alias it")
+    dx = out if out is not None else torch.empty((n, h, wd, ci), dtype=_BF16, device=dy.device)
+    ws, wsn = _WS.get(L.fosvos_conv3x3_workspace_bytes(n, h, wd, co, ci), dy.device)
+    dev, st = _ctx(dy)
+    t0 = _pb()
+    check(L.fosvos_conv3x3_dgrad_unpool(dy.data_ptr(), w_dgrad_packed.data_ptr(), x.data_ptr(), d_pooled.data_ptr(), dx.data_ptr(),
+                                        n, h, wd, ci, co, ws, wsn, dev, st), "conv3x3_dgrad_unpool")
+    _pe(t0, "conv3x3_dgrad_unpool", 2.0 * n * h * wd * 9 * ci * co, n * h * wd * 2 * (cy + 2 * ci + ci // 4) + 2 * 9 * ci * co)
+    return dx
+
+
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ci: int, co: int, with_bias: bool = True,
                   dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None, accumulate: bool = False):
     _need(x, _BF16, "conv3x3_wgrad x"); _need(dy, _BF16, "conv3x3_wgrad dy")

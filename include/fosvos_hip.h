@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FOSVOS_ABI_VERSION 16
+#define FOSVOS_ABI_VERSION 17
 
 #define FOSVOS_OK 0
 #define FOSVOS_E_SHAPE (-1)     /* unsupported or inconsistent shape            */
@@ -206,6 +206,17 @@ int fosvos_conv3x3_dgrad(const uint16_t *dy, const uint16_t *w_dgrad_packed, con
 int fosvos_conv3x3_dgrad_bits(const uint16_t *dy, const uint16_t *w_dgrad_packed, const uint8_t *relu_bits,
                               const uint16_t *addend, uint16_t *dx, int N, int H, int W, int Ci, int Co, void *workspace,
                               size_t workspace_bytes, int device, void *stream);
+/* Data gradient of a conv whose INPUT x also feeds a MaxPool2d(2, 2, ceil_mode=True) - side_prep[i] on a stage output
+ * (src/networks/osvos_vgg.py:61-83: `side_prep[i](x)` beside `stages[i+1](x)`) - with the pool's backward in the same pass:
+ *   dx = [x > 0] * dgrad(dy) + maxpool2x2_ceil_bwd(x, d_pooled)         (fosvos_maxpool2x2_ceil_bwd with relu_mask = 1)
+ *   x        bf16 NHWC [N,H,W,Ci]: the post-ReLU stage output (ReLU mask and the pool's arg-max source)
+ *   d_pooled bf16 NHWC [N,ceil(H/2),ceil(W/2),Ci]: gradient wrt the pooled map
+ * Bit for bit the result of the pool backward followed by fosvos_conv3x3_dgrad(dy, w, x, addend = that, dx), which is also
+ * what runs for shapes whose plan has no fused form (split-K launches, Ci not a multiple of 64).  dx must not alias x.
+ * replaces: autograd's backward of the two consumers of a stage output. */
+int fosvos_conv3x3_dgrad_unpool(const uint16_t *dy, const uint16_t *w_dgrad_packed, const uint16_t *x,
+                                const uint16_t *d_pooled, uint16_t *dx, int N, int H, int W, int Ci, int Co,
+                                void *workspace, size_t workspace_bytes, int device, void *stream);
 /* dw[Co,Ci,3,3] (fp32 OIHW) and db[Co] (may be NULL) from x[N,H,W,Ci] and dy[N,H,W,Co_pad] (bf16).
  * Deterministic: split partial sums are written as slabs to the workspace and reduced in a fixed
  * order.  accumulate != 0 adds into dw/db instead of overwriting.

@@ -614,6 +614,52 @@ def test_relu_mask_as_bits(ops, n, h, w, co):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("n,h,w,ci,tile", [
+    (1, 48, 86, 128, (8, 16, 64)), (2, 61, 107, 64, (8, 16, 64)), (1, 33, 47, 256, (8, 16, 64)), (3, 17, 16, 64, (8, 16, 64)),
+    (5, 240, 427, 128, (16, 16, 64)), (5, 120, 214, 256, (8, 32, 64)), (5, 60, 107, 512, (16, 16, 64)),  # the step's launches
+    (2, 61, 107, 32, None),  # no fused form for 32 channels: the library runs the two passes itself
+])
+def test_dgrad_with_fused_pool_backward(ops, n, h, w, ci, tile):
+    """fosvos_conv3x3_dgrad_unpool: side_prep's data gradient on a stage output x with the backward of the stage's 2x2 ceil-mode
+    max pool in its epilogue (src/networks/osvos_vgg.py:61-83: x feeds side_prep[i] AND stages[i+1]'s pool).  Bit for bit the
+    two passes it replaces - fosvos_maxpool2x2_ceil_bwd(x, d_pooled, relu mask) then fosvos_conv3x3_dgrad(relu_src=x, addend=that) -
+    on inputs full of ties (x takes few distinct values and many zeros: first maximum in scan order wins, a dead window gets
+    nothing) and ragged last rows / columns; on all three tiles that have the fused epilogue, the three launches of the training
+    step among them (tile asserted), and on a shape without one.  And against autograd on fp32 at one shape."""
+    g = torch.Generator().manual_seed(700 + h + ci)
+    co = 16
+    x = (torch.relu(torch.randn(n, h, w, ci, generator=g)) * 2).round().div(2).to(torch.bfloat16).to(DEV)  # multiples of 0.5: ties
+    assert 0.3 < (x == 0).float().mean().item() < 0.7
+    dpool = torch.randn(n, (h + 1) // 2, (w + 1) // 2, ci, generator=g).to(torch.bfloat16).to(DEV)
+    wt = torch.randn(co, ci, 3, 3, generator=g) * 0.1
+    _, wd = ops.pack_conv3x3_weights(wt.to(DEV))
+    dy = torch.zeros(n, h, w, 32, dtype=torch.bfloat16, device=DEV)
+    dy[..., :co] = torch.randn(n, h, w, co, generator=g).to(torch.bfloat16).to(DEV)
+    if tile is not None:
+        plan = ops.conv3x3_plan(n, h, w, co, ci)
+        assert plan["tile"] == tile and plan["k_splits"] == 1, plan
+    routed = ops.maxpool_bwd(x, dpool, relu_mask=True)
+    want = ops.conv3x3_dgrad(dy, wd, ci, co, relu_src=x, addend=routed)
+    got = ops.conv3x3_dgrad_unpool(dy, wd, ci, co, x, dpool)
+    assert torch.equal(got, want)
+    out = torch.full_like(got, 7.0)  # into a given buffer
+    assert ops.conv3x3_dgrad_unpool(dy, wd, ci, co, x, dpool, out=out) is out and torch.equal(out, want)
+    with pytest.raises(ValueError):
+        ops.conv3x3_dgrad_unpool(dy, wd, ci, co, x, dpool, out=x)
+    if (n, h, w, ci) == (2, 61, 107, 64):  # autograd: both consumers of relu(pre), on the same bf16-rounded operands
+        pre = x.float().permute(0, 3, 1, 2).cpu()
+        pre = torch.where(pre > 0, pre, -torch.ones_like(pre)).requires_grad_(True)
+        xr = torch.relu(pre)
+        side = F.conv2d(xr, wt.to(torch.bfloat16).float(), padding=1)
+        pooled = F.max_pool2d(xr, 2, 2, ceil_mode=True)
+        (side * dy[..., :co].float().permute(0, 3, 1, 2).cpu()).sum().backward(retain_graph=True)
+        g_side = pre.grad.clone(); pre.grad = None
+        (pooled * dpool.float().permute(0, 3, 1, 2).cpu()).sum().backward()
+        # (the kernel rounds the conv term to bf16 before the add, like the two passes)
+        ref = g_side.to(torch.bfloat16).float() + pre.grad
+        assert rel_err(got.float().permute(0, 3, 1, 2).cpu(), ref) < 6e-3
+
+
 @pytest.mark.parametrize("n,H,W,uniform", [(1, 48, 86, 0b1111), (2, 61, 107, 0b0101), (1, 33, 47, 0b1010), (3, 17, 16, 0b1000)])
 def test_head_channel_uniform_filters(ops, n, H, W, uniform):
     """filt_uniform: where a scale's 16 channel filters are identical (what interp_surgery writes and lr 0 keeps,
