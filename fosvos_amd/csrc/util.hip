@@ -308,6 +308,7 @@ __global__ void k_pack_w(const float *__restrict__ w, uint16_t *__restrict__ dst
 // in 512-byte runs.  (k_pack_w above gathers 8 floats 36 bytes apart per thread: ~0.5 TB/s.)
 struct PackTable {
     int n;
+    int co_tile;  // output channels per block: 32, or 8 when the launch would otherwise be a few dozen blocks
     fosvos_pack_entry e[24];
     int block_begin[25];
 };
@@ -318,28 +319,44 @@ __global__ __launch_bounds__(256) void k_pack_w_tiled(const PackTable t) {
     while (e + 1 < t.n && (int)blockIdx.x >= t.block_begin[e + 1]) ++e;
     const fosvos_pack_entry &q = t.e[e];
     const int local = blockIdx.x - t.block_begin[e];
-    const int nkb = q.Ci / 32;
+    const int nkb = q.Ci / 32, co_t = t.co_tile;
     const int cb = local / nkb, kb = local % nkb;
-    const int co0 = cb * 32, ci0 = kb * 32;
-    for (int i = threadIdx.x; i < 32 * 288; i += 256) {
-        const int r = i / 288, c = i - r * 288;
-        tile[r][c] = (co0 + r < q.Co) ? q.w[((int64_t)(co0 + r) * q.Ci + ci0) * 9 + c] : 0.f;
+    const int co0 = cb * co_t, ci0 = kb * 32;
+    // a row is 288 contiguous floats, 16-byte aligned when w is (ci0 * 9 floats = a multiple of 1152 bytes)
+    if (((uintptr_t)q.w & 15) == 0) {
+        for (int i = threadIdx.x; i < co_t * 72; i += 256) {
+            const int r = i / 72, c = (i - r * 72) * 4;
+            const float4 v = (co0 + r < q.Co) ? *reinterpret_cast<const float4 *>(q.w + ((int64_t)(co0 + r) * q.Ci + ci0) * 9 + c)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < co_t * 288; i += 256) {
+            const int r = i / 288, c = i - r * 288;
+            tile[r][c] = (co0 + r < q.Co) ? q.w[((int64_t)(co0 + r) * q.Ci + ci0) * 9 + c] : 0.f;
+        }
     }
     __syncthreads();
     const int co_pad = (q.Co + 15) / 16 * 16, ci_pad = (q.Ci + 15) / 16 * 16;
-    for (int g = threadIdx.x; g < 9 * 4 * 32; g += 256) {
-        const int l = g & 31, kc = (g >> 5) & 3, tap = g >> 7;
-        if (q.w_fwd && co0 + l < co_pad) {  // contraction over ci: k-chunk kb, group kc = 8 ci; output channel co0 + l
+    if (q.w_fwd) {  // contraction over ci: k-chunk kb, group kc = 8 ci; output channel co0 + l
+        for (int g = threadIdx.x; g < 9 * 4 * co_t; g += 256) {
+            const int l = g % co_t, kc = (g / co_t) & 3, tap = g / (4 * co_t);
+            if (co0 + l >= co_pad) continue;
             float f[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = tile[l][(kc * 8 + j) * 9 + tap];
             *reinterpret_cast<uint4 *>(q.w_fwd + ((((int64_t)kb * 9 + tap) * 4 + kc) * co_pad + co0 + l) * 8) = pack8(f);
         }
-        if (q.w_dgrad) {  // contraction over co: k-chunk cb, group kc = 8 co; output channel ci0 + l; rotated taps
+    }
+    if (q.w_dgrad) {  // contraction over co: k-chunk (co0 + 8 kc) / 32, group = its 8 co; output channel ci0 + l; rotated taps
+        const int n_kc = co_t / 8;
+        for (int g = threadIdx.x; g < 9 * n_kc * 32; g += 256) {
+            const int l = g & 31, kc = (g >> 5) % n_kc, tap = (g >> 5) / n_kc;
             float f[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = tile[kc * 8 + j][l * 9 + tap];
-            *reinterpret_cast<uint4 *>(q.w_dgrad + ((((int64_t)cb * 9 + (8 - tap)) * 4 + kc) * ci_pad + ci0 + l) * 8) =
+            const int co = co0 + kc * 8;
+            *reinterpret_cast<uint4 *>(q.w_dgrad + ((((int64_t)(co >> 5) * 9 + (8 - tap)) * 4 + ((co >> 3) & 3)) * ci_pad + ci0 + l) * 8) =
                 pack8(f);
         }
     }
@@ -349,17 +366,28 @@ extern "C" int fosvos_pack_conv3x3_weights_multi(const fosvos_pack_entry *entrie
     FOSVOS_REQUIRE(entries && n > 0 && n <= 24, FOSVOS_E_ARG, "pack_conv3x3_weights_multi: 1..24 entries, got %d", n);
     PackTable t;
     t.n = n;
-    int blocks = 0;
     for (int i = 0; i < n; ++i) {
         const fosvos_pack_entry &q = entries[i];
         FOSVOS_REQUIRE(q.w && (q.w_fwd || q.w_dgrad), FOSVOS_E_ARG, "pack_conv3x3_weights_multi: null pointer in entry %d", i);
         FOSVOS_REQUIRE(q.Co > 0 && q.Ci > 0 && q.Ci % 32 == 0, FOSVOS_E_SHAPE,
                        "pack_conv3x3_weights_multi: entry %d has Co=%d Ci=%d (Ci must be a multiple of 32)", i, q.Co, q.Ci);
         t.e[i] = q;
-        t.block_begin[i] = blocks;
-        blocks += (int)cdiv(q.Co, 32) * (q.Ci / 32);
     }
-    t.block_begin[n] = blocks;
+    // (the rows of a 32-channel chunk of the dgrad image are all written, zeros where co >= Co: blocks cover roundup(Co, 32))
+    auto count = [&](int co_tile) {
+        int blocks = 0;
+        for (int i = 0; i < n; ++i) {
+            t.block_begin[i] = blocks;
+            blocks += roundup(entries[i].Co, 32) / co_tile * (entries[i].Ci / 32);
+        }
+        t.block_begin[n] = blocks;
+        return blocks;
+    };
+    // the layers the late half of a split optimizer step repacks (conv1_2 .. conv2_2, side_prep[0]) are 32 blocks of 32
+    // channels: a launch bound by one block's latency, in front of the first kernel of the next cycle
+    t.co_tile = 32;
+    int blocks = count(32);
+    if (blocks < 256) { t.co_tile = 8; blocks = count(8); }
     FOSVOS_ENTER(device);
     FOSVOS_PROF("k_pack_w_tiled", stream, 0.0);
     hipLaunchKernelGGL(k_pack_w_tiled, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);

@@ -95,12 +95,27 @@ def test_pack_weights(ops, co, ci):
     assert torch.equal(dgr.float().cpu(), bf(_pack_ref(w, True)))
 
 
-def test_pack_weights_multi(ops):
+@pytest.mark.parametrize("shapes,offset", [
+    ([(64, 64), (128, 64), (16, 128), (256, 128), (16, 512), (96, 32)], 0),
+    ([(64, 64), (128, 64), (128, 128), (16, 128)], 0),   # what the late half of the split optimizer step repacks: 8-channel blocks
+    ([(512, 512), (16, 512), (256, 128), (40, 64)], 0),  # > 256 blocks: 32-channel blocks
+    ([(64, 64), (16, 128)], 1), ([(512, 256), (16, 256)], 3),  # masters that are not 16-byte aligned (views into a flat buffer)
+])
+def test_pack_weights_multi(ops, shapes, offset):
     """One launch for many layers (what the module does after an optimizer step) == the per-layer packer, bit for bit;
-    covers a 16-channel side layer (half-empty 32-channel block) and non-square layers."""
-    shapes = [(64, 64), (128, 64), (16, 128), (256, 128), (16, 512), (96, 32)]
+    covers a 16-channel side layer (half-empty 32-channel block), non-square layers, both block sizes of the kernel and
+    masters at any 4-byte alignment."""
     ws = [gen(co, ci, 3, 3, seed=40 + i) for i, (co, ci) in enumerate(shapes)]
-    got = ops.pack_conv3x3_weights_multi([w.to(DEV) for w in ws])
+
+    def on_device(w):
+        if not offset:
+            return w.to(DEV)
+        flat = torch.empty(w.numel() + offset, device=DEV)
+        flat[offset:] = w.reshape(-1).to(DEV)
+        v = flat[offset:].view(w.shape)
+        assert v.data_ptr() % 16 == 4 * offset and v.is_contiguous()
+        return v
+    got = ops.pack_conv3x3_weights_multi([on_device(w) for w in ws])
     assert len(got) == len(ws)
     for w, (fwd, dgr) in zip(ws, got):
         assert torch.equal(fwd.float().cpu(), bf(_pack_ref(w, False)))
