@@ -792,8 +792,8 @@ int launch(const ConvArgs &a0, const ConvPlan &plan, hipStream_t st, int in_ch) 
     }
     if (g_prof_on) {  // the name rocprofv3 prints for this instantiation
         static char name[80];
-        snprintf(name, sizeof(name), "k_conv3x3_igemm<Tile<%d, %d, %d, %d, %d>, %s%s>", T::TH, T::TW, T::BN, T::WM, T::WN,
-                 OUT_F32 ? "true" : "false", UNPOOL ? ", true" : "");
+        snprintf(name, sizeof(name), "k_conv3x3_igemm<Tile<%d, %d, %d, %d, %d>, %s, %s>", T::TH, T::TW, T::BN, T::WM, T::WN,
+                 OUT_F32 ? "true" : "false", UNPOOL ? "true" : "false");
         prof_begin(name, st, 2.0 * a.N * a.H * a.W * 9.0 * in_ch * a.Cout);
     }
     {

@@ -520,8 +520,8 @@ int conv_pp_forward(const uint16_t *x, const uint16_t *w_packed, const float *bi
                                              pp::LDS_BYTES));
         once[dev][which] = true;
     }
-    FOSVOS_PROF(mask_bits ? "k_conv3x3_pp<false, false, true>" : y_pool ? "k_conv3x3_pp<true, true>"
-                : relu    ? "k_conv3x3_pp<true, false>" : "k_conv3x3_pp<false, false>", st,
+    FOSVOS_PROF(mask_bits ? "k_conv3x3_pp<false, false, true>" : y_pool ? "k_conv3x3_pp<true, true, false>"
+                : relu    ? "k_conv3x3_pp<true, false, false>" : "k_conv3x3_pp<false, false, false>", st,
                 2.0 * N * H * W * 9.0 * Cin_pad * Cout);
     hipLaunchKernelGGL(kern, dim3(conv_pp_workgroups()), dim3(pp::NT), pp::LDS_BYTES, st, a);
     FOSVOS_LAUNCH_CHECK();
