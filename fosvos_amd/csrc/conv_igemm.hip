@@ -722,18 +722,24 @@ ConvPlan make_plan(int N, int H, int W, int in_ch, int out_ch) {
         // 256-pixel tiles as soon as there is one per CU (measured: 420 workgroups of 8x32 beat 840 of 8x16 by 8 % at
         // 120x214x256 alone; at 60x107x512, 256 of them beat 448 of 8x16 by 1 % of the whole step beside the wgrad
         // stream, which fills the second slot of each CU); below that the 128-pixel tile, 3 per CU
-        // ... unless the 128-pixel tiles still fit in ONE round (3 per CU = 768): five frames of the 30x54x512 layers are 320
-        // big workgroups (62 % of the 512 slots, 16 chunks each) or 640 small ones: 53 against 60 us per launch alone
-        static const bool one_round = lab_env_int("FOSVOS_MID_ONE_ROUND", 1) != 0;
-        const bool mid_fits_a_round = one_round && blocks(8, 16, 64) <= 768 && blocks(8, 32, 64) < kMinBlocks * 3 / 4;
-        if (blocks(8, 32, 64) >= kMinBlocks / 2 && !mid_fits_a_round) {
+        bool big = blocks(8, 32, 64) >= kMinBlocks / 2;
+        if (big) {
             // ... as 8 x 32 or as 16 x 16 pixels, whichever overhangs the map less (a tile computes all of its 256 pixels:
             // 60 x 107 is 64 x 128 = 8192 pixels of work in 8 x 32 tiles, 64 x 112 = 7168 in 16 x 16 ones)
             const int64_t area_wide = cdiv(H, 8) * 8 * cdiv(W, 32) * 32, area_sq = cdiv(H, 16) * 16 * cdiv(W, 16) * 16;
             static const bool allow_sq = lab_env_int("FOSVOS_NO_SQUARE_TILE", 0) == 0;
             if (allow_sq && area_sq < area_wide) { p.tile = kSquare; nb = blocks(16, 16, 64); }
             else { p.tile = kBig; nb = blocks(8, 32, 64); }
-        } else { p.tile = kMid; nb = blocks(8, 16, 64); }
+            // ... unless the 128-pixel tiles fit in ONE round (3 per CU = 768) and the 256-pixel tiles chosen are not even one
+            // per CU (one frame's 60x107x512 layers: 224 tiles of 16 x 16, which would go on to split K).  Until round 4 the
+            // condition was "fewer than 384 of the 8 x 32 tiles" (lab switch FOSVOS_MID_ONE_ROUND=1), which also took the
+            // five-frame 30x54x512 data gradients - 320 big workgroups, 62 % of the 512 slots, 16 chunks each, or 640 small
+            // ones: alone the small ones win, 53 against 60 us per launch; beside the weight-gradient stream, where these
+            // launches run, they lose: the step +0.5 % with the big tile (profiles/r04_lab_step_ab_tunables.txt).
+            static const bool one_round = lab_env_int("FOSVOS_MID_ONE_ROUND", 0) != 0;
+            if (blocks(8, 16, 64) <= 768 && (one_round ? blocks(8, 32, 64) < kMinBlocks * 3 / 4 : nb < kMinBlocks / 2)) big = false;
+        }
+        if (!big) { p.tile = kMid; nb = blocks(8, 16, 64); }
     } else if (out_ch == 32) {
         if (pixels >= 256 * 256) { p.tile = kHalf; nb = blocks(8, 32, 32); }
         else { p.tile = kHalfS; nb = blocks(4, 16, 32); }

@@ -148,12 +148,12 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
 
     # lab switch (A/B only): 0 = separate gradient memsets behind the optimizer step and an unannounced backward seed
     fuse_small = os.environ.get('FOSVOS_LOOP_FUSE', '1') != '0'
-    # FOSVOS_STAGE_LOSS=1: the loss of a batched pass in three stages (class counts in front of the forward pass, values and
-    # host copy behind the backward pass; fosvos_cbce_loss_frames_parts).  +0.5 % when the chain between the passes was 150 us
-    # long; neutral since the head kernels got shorter - the count then sits in front of the cycle's first kernel and the
-    # values at the end of the pass's stream, both as exposed as the place they left (profiles/r04_lab_step_ab_head_loss.txt).
-    # Off by default: the same arithmetic either way (tested bit for bit).
-    stage_losses = os.environ.get('FOSVOS_STAGE_LOSS', '0') == '1'
+    # The loss of a batched pass in three stages (class counts in front of the forward pass, values and host copy behind the
+    # backward pass; fosvos_cbce_loss_frames_parts): two launches and the copy leave the chain of small kernels between the
+    # passes.  +0.5 % when that chain was 150 us long, neutral after the head kernels got shorter, +0.3 % on the final build
+    # (5 of 5 interleaved rounds, profiles/r04_lab_step_ab_tunables.txt).  The same arithmetic either way (tested bit for
+    # bit); FOSVOS_STAGE_LOSS=0 = the loss as one call between the passes.
+    stage_losses = os.environ.get('FOSVOS_STAGE_LOSS', '1') == '1'
     # A cycle whose micro-batches cannot run as ONE batched pass (frames of different sizes - the reference's augmentation
     # draws a new scale per iteration - or FOSVOS_MICROBATCH_GROUP < nAveGrad) runs its passes on two alternating streams:
     # the weights do not change inside a cycle and every pass has its own arena, so the forward pass of one micro-batch may

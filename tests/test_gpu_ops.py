@@ -310,7 +310,8 @@ HOT_CASES = [
     (5, 120, 214, 128, 128, (8, 32, 64)),   # five frames per launch, stage-3 map: 8x32 tiles, 214 = 6 * 32 + 22
     (1, 480, 854, 64, 64, (8, 32, 64)),     # conv1_2 at full size: 1620 workgroups, XCD-swizzled 1-D grid
     (5, 60, 107, 256, 256, (16, 16, 64)),   # five frames, stage-4 map: 16x16 tiles overhang 60x107 less than 8x32 ones
-    (5, 30, 54, 512, 512, (8, 16, 64)),     # five frames, stage 5 as the step runs it: 640 128-pixel tiles in one round
+    (5, 30, 54, 512, 512, (8, 32, 64)),     # five frames, stage 5 as the backward pass runs it: 320 workgroups of 256 pixels
+    (3, 30, 54, 512, 512, (8, 16, 64)),     # ... and as the forward pass's three-frame chain does: 384 128-pixel tiles
 ]
 
 

@@ -53,7 +53,8 @@ def test_conv_plan_of_the_480p_step():
     assert _plan(1, 240, 427, 128, 128)[:4] == (16, 16, 64, 1)
     assert _plan(5, 120, 214, 128, 256)[:4] == (8, 32, 64, 1)
     assert _plan(5, 60, 107, 512, 512)[:4] == (16, 16, 64, 1)
-    assert _plan(5, 30, 54, 512, 512)[:4] == (8, 16, 64, 1)        # stage 5 of five frames: 640 128-pixel tiles, one round
+    assert _plan(5, 30, 54, 512, 512)[:4] == (8, 32, 64, 1)        # stage 5 of five frames: 320 workgroups of 256 pixels
+    assert _plan(3, 30, 54, 512, 512)[:4] == (8, 16, 64, 1)        # ... of a three-frame forward chain: 384 128-pixel tiles
     assert _plan(1, 120, 214, 64, 64)[:3] == (8, 16, 64)           # 105 blocks of 256 px: the 128-pixel tile
     assert _plan(1, 30, 54, 512, 512)[3] > 1                       # stage 5 of one frame: split-K
     assert _plan(1, 240, 427, 128, 16)[:3] == (8, 32, 16)          # side_prep at large maps
