@@ -563,7 +563,14 @@ def native_backward(P, packs, saved, d_outs, inplace: bool, defer_join: bool = F
         # the four score_dsn layers are separate [1,16,1,1] / [1] parameters: gather through one [4,16] / [4] scratch
         dsn_tmp = (torch.zeros((4, 16), dtype=torch.float32, device=dev), torch.zeros((4,), dtype=torch.float32, device=dev))
         g.dsn_w, g.dsn_b = dsn_tmp[0].data_ptr(), dsn_tmp[1].data_ptr()
-    g.accumulate = 1 if inplace else 0
+    # overwrite_grads (set by a loop for the FIRST backward pass of an accumulation cycle, osvos_vgg.OSVOS_VGG.overwrite_grads):
+    # the pass writes its gradients instead of adding them to what the buffers hold - the buffers then need no zeroing
+    # between cycles (one write and one read of every gradient less per cycle).  Only the gradients this call produces are
+    # written: the side-output layers' (score_dsn) go through a scratch and an add below, so the two do not combine.
+    overwrite = inplace and getattr(packs, "overwrite_grads", False)
+    if overwrite and with_so:
+        raise RuntimeError("OSVOS_VGG backward: overwrite_grads with side-output gradients (score_dsn accumulates through a scratch)")
+    g.accumulate = 1 if inplace and not overwrite else 0
     aux = packs.arenas.aux_stream(dev.index if dev.index is not None else torch.cuda.current_device())
     g.defer_join = 1 if (defer_join and inplace and aux) else 0
     g.bucket_events = 1 if getattr(packs, "publish_grad_buckets", False) else 0

@@ -126,6 +126,18 @@ class OSVOS_VGG(nn.Module):
         return bool(engine.USE_NATIVE_LOOP)
 
     @property
+    def overwrite_grads(self):
+        return getattr(self._packs, "overwrite_grads", False)
+
+    @overwrite_grads.setter
+    def overwrite_grads(self, value):
+        """True: the next backward passes WRITE the parameter gradients they compute (all but score_dsn's, which only a loss
+        on the side outputs produces - such a pass refuses the flag) instead of adding them to ``p.grad``: what an
+        accumulation cycle's first pass may do when nothing else adds to the buffers beside it, so that the buffers need no
+        zeroing between cycles.  The online loop sets it around a cycle that is one batched pass."""
+        self._packs.overwrite_grads = bool(value)
+
+    @property
     def last_pass_of_cycle(self):
         return getattr(self._packs, "last_pass_of_cycle", False)
 

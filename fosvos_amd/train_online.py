@@ -154,6 +154,15 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     # (5 of 5 interleaved rounds, profiles/r04_lab_step_ab_tunables.txt).  The same arithmetic either way (tested bit for
     # bit); FOSVOS_STAGE_LOSS=0 = the loss as one call between the passes.
     stage_losses = os.environ.get('FOSVOS_STAGE_LOSS', '1') == '1'
+    # Gradient buffers without zeroing: a cycle that is ONE batched pass (the usual case: nAveGrad frames of one shape) WRITES
+    # its gradients (net.overwrite_grads) instead of adding them to buffers the previous optimizer step had to zero - one
+    # write and one read of every gradient less per cycle, in the HBM-bound tail of the cycle (+0.6 %,
+    # profiles/r04_lab_step_ab_tunables.txt).  The optimizer step then leaves the gradients in place ("stale"), and a cycle
+    # of several passes - which do add - zeroes the buffer first.  The same values either way (a sum that starts from zero):
+    # tested bit for bit.  FOSVOS_GRAD_OVERWRITE=0: zero in the optimizer step, always add.
+    lazy_zero = (fuse_small and flat.flat.is_cuda and hasattr(net, 'overwrite_grads')
+                 and os.environ.get('FOSVOS_GRAD_OVERWRITE', '1') != '0')
+    grads_stale = [False]
     # A cycle whose micro-batches cannot run as ONE batched pass (frames of different sizes - the reference's augmentation
     # draws a new scale per iteration - or FOSVOS_MICROBATCH_GROUP < nAveGrad) runs its passes on two alternating streams:
     # the weights do not change inside a cycle and every pass has its own arena, so the forward pass of one micro-batch may
@@ -366,14 +375,14 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
                         sync.wait_bucket(b)
                     else:
                         net.wait_grad_bucket(flat.bucket_ids[b])
-                optimizer.step(only=early_params, tag='early', zero_grad=fuse_small)  # (the step kernel zeroes what it read)
+                optimizer.step(only=early_params, tag='early', zero_grad=fuse_small and not lazy_zero)  # (the step kernel zeroes what it read)
                 if not fuse_small:
                     flat.zero(early_buckets)
                 net.prepack_weights(early_prefixes)
                 wait_side_stream()
                 net.join_gradients()
                 sync.finish()
-                optimizer.step(only=late_params, tag='late', zero_grad=fuse_small)
+                optimizer.step(only=late_params, tag='late', zero_grad=fuse_small and not lazy_zero)
                 if not fuse_small:
                     flat.zero(late_buckets)
             else:
@@ -381,7 +390,9 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
                 net.join_gradients()
                 sync.finish()  # the bucketed all-reduce begun right behind the cycle's last backward pass
                 optimizer.step()
-                flat.zero()
+                if not lazy_zero:
+                    flat.zero()
+            grads_stale[0] = lazy_zero
             counter_gradient = 0
 
     def run_window(window) -> None:
@@ -399,6 +410,15 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         # better with its two forward chains side by side, which needs the auxiliary stream the previous pass's weight
         # gradients would still occupy)
         multi = pass_streams is not None and not dp_on and len(groups) > 1 and max(len(g) for g in groups) <= 2
+        if lazy_zero:
+            # a window that opens a cycle: one pass that is the whole cycle writes its gradients; anything else adds - to
+            # zeros (queued here, on the caller's stream, in front of everything the window's passes do on either stream)
+            whole_cycle = counter_gradient == 0 and len(groups) == 1 and len(groups[0]) == local_accum
+            net.overwrite_grads = whole_cycle
+            if counter_gradient == 0:
+                if grads_stale[0] and not whole_cycle:
+                    flat.zero()
+                grads_stale[0] = False
         if multi:
             # both pass streams must see the last optimizer step and the repacked weight images: pack once here, on the
             # caller's stream, instead of inside the first forward pass (which the second stream would have to wait for)
@@ -439,6 +459,10 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
         run_window(window)
 
     net.defer_wgrad_join = False  # joins
+    if lazy_zero:
+        net.overwrite_grads = False
+        if grads_stale[0]:  # leave the buffers as optimizer.zero_grad() would (src/train_online.py:100-104)
+            flat.zero()
     if hasattr(net, 'forward_one_stream'):
         net.forward_one_stream = False
     net.compute_side_outputs = True

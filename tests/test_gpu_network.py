@@ -588,8 +588,10 @@ def test_scheduling_switches_do_not_change_the_weights(monkeypatch):
     loader = [{"image": x, "gt": gt} for x, gt in frames]
     runs = {}
     for tag, env in (("default", {}), ("one_step", {"FOSVOS_SPLIT_STEP": "0"}), ("one_stream_fwd", {"FOSVOS_FWD_AUX": "0"}),
-                     ("staged_loss", {"FOSVOS_STAGE_LOSS": "1"}), ("general_head", {"FOSVOS_HEAD_UNIFORM": "0"})):
-        for k_, v_ in (("FOSVOS_SPLIT_STEP", "1"), ("FOSVOS_FWD_AUX", "1"), ("FOSVOS_STAGE_LOSS", "0"), ("FOSVOS_HEAD_UNIFORM", "1")):
+                     ("staged_loss", {"FOSVOS_STAGE_LOSS": "1"}), ("general_head", {"FOSVOS_HEAD_UNIFORM": "0"}),
+                     ("zero_in_step", {"FOSVOS_GRAD_OVERWRITE": "0"})):
+        for k_, v_ in (("FOSVOS_SPLIT_STEP", "1"), ("FOSVOS_FWD_AUX", "1"), ("FOSVOS_STAGE_LOSS", "0"), ("FOSVOS_HEAD_UNIFORM", "1"),
+                       ("FOSVOS_GRAD_OVERWRITE", "1")):
             monkeypatch.setenv(k_, env.get(k_, v_))
         net, _ = make_net(23)
         prov = VGGOnlineProvider.__new__(VGGOnlineProvider)
@@ -603,7 +605,8 @@ def test_scheduling_switches_do_not_change_the_weights(monkeypatch):
     base_w, base_loss = runs["default"]
     # ... and the loss of a batched pass in three stages around the passes (FOSVOS_STAGE_LOSS=1: class counts in front of the
     # forward pass, values behind the backward pass) is the same loss
-    for tag in ("one_step", "one_stream_fwd", "staged_loss"):
+    # ... and so is the cycle's one pass writing its gradients (no zeroing between cycles) against zero-and-add
+    for tag in ("one_step", "one_stream_fwd", "staged_loss", "zero_in_step"):
         w, loss = runs[tag]
         assert loss == base_loss, tag
         for n_ in base_w:
@@ -621,6 +624,52 @@ def test_scheduling_switches_do_not_change_the_weights(monkeypatch):
         step = (base_w[n_] - w0[n_]).double().norm().item()
         diff = (base_w[n_] - w[n_]).double().norm().item()
         assert diff <= 0.05 * step + 1e-12, (n_, diff, step)
+
+
+def test_gradient_buffers_without_zeroing(monkeypatch):
+    """The online loop does not zero its gradient buffers between cycles when a cycle is ONE batched pass: that pass writes
+    its gradients (OSVOS_VGG.overwrite_grads) and the optimizer step leaves them in place; a cycle of several passes (frames
+    of two shapes) adds, after one memset.  Cycles of both kinds in one run - one pass, two passes, one pass, and a last
+    cycle left open - give bit for bit the weights and losses of zero-in-the-step-and-always-add
+    (FOSVOS_GRAD_OVERWRITE=0, what src/train_online.py:100-104 does), the buffers hold the same at return - the open cycle's
+    sums - and a run that ends on a cycle boundary returns with zeroed buffers, as optimizer.zero_grad() leaves them."""
+    import train_online
+    from util.network_provider import VGGOnlineProvider
+    a = [O.synthetic_frame(1, 40, 70, seed=300 + i) for i in range(12)]
+    b = [O.synthetic_frame(1, 33, 47, seed=320 + i) for i in range(2)]
+    order = a[:5] + [a[5], b[0], a[6], b[1], a[7]] + a[8:12] + [a[0], a[1]]  # 5 + (3 + 2) + 5 + an open cycle of 2
+    loader = [{"image": x, "gt": gt} for x, gt in order]
+    runs = {}
+    for tag, v in (("lazy", "1"), ("zeroed", "0")):
+        monkeypatch.setenv("FOSVOS_GRAD_OVERWRITE", v)
+        net, _ = make_net(29)
+        prov = VGGOnlineProvider.__new__(VGGOnlineProvider)
+        prov.network = net
+        prov.name = "vgg16"
+        opt = prov.get_optimizer(learning_rate=1e-8)
+        train_online.data_parallel = False
+        ret = train_online._train(prov, loader, opt, _NullWriter(), "lazy_zero", 0, 1, 5, 10 ** 9)
+        assert ret["iterations"] == len(order)
+        runs[tag] = ({n_: p.detach().clone() for n_, p in net.named_parameters()}, ret["loss"],
+                     {n_: p.grad.detach().clone() for n_, p in net.named_parameters() if p.grad is not None})
+        assert not net.overwrite_grads
+    assert runs["lazy"][1] == runs["zeroed"][1]
+    for n_, w in runs["zeroed"][0].items():
+        assert torch.equal(runs["lazy"][0][n_], w), n_
+    # the open cycle's two passes are what the buffers hold at the end, in both runs (the loop returns mid-cycle, as the
+    # reference does when the iteration count is no multiple of nAveGrad)
+    moved = 0
+    for n_, g in runs["zeroed"][2].items():
+        assert torch.equal(runs["lazy"][2][n_], g), n_
+        moved += int(g.abs().sum().item() > 0)
+    assert moved >= 30
+    monkeypatch.setenv("FOSVOS_GRAD_OVERWRITE", "1")
+    net, _ = make_net(29)
+    prov = VGGOnlineProvider.__new__(VGGOnlineProvider)
+    prov.network = net
+    prov.name = "vgg16"
+    train_online._train(prov, loader[:5], prov.get_optimizer(learning_rate=1e-8), _NullWriter(), "lazy_zero", 0, 2, 5, 10 ** 9)
+    assert all(float(p.grad.abs().sum()) == 0.0 for p in net.parameters() if p.grad is not None)
 
 
 @pytest.mark.parametrize("case", ["two_pairs", "two_singles", "cycle_over_two_windows"])
