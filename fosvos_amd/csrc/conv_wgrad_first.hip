@@ -36,7 +36,7 @@ struct FirstArgs {
     float *bias_part;    // [S][64] or null
     int N, H, W;
     int tiles_x, tiles_y, n_tiles, tiles_per_split;
-    int newest_first;  // tile walk: 0 = a contiguous ascending range per workgroup; 1 = see the kernel
+    int newest_first;  // tile walk: 0 = a contiguous ascending range per workgroup; G > 0 = chunks of G tiles, newest first (see the kernel)
 };
 
 typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_ptr;
@@ -90,14 +90,20 @@ __global__ __launch_bounds__(256) void k_wgrad_first(const FirstArgs a) {
     const int n_ci = n_col / 9, n_ky = (n_col % 9) / 3, n_kx = n_col % 3;
     const int rd_b = Y_BYTES + ((n_kx * 3 + n_ci) * (TH + 2) + n_ky) * 32 + (lane >> 5) * 16;  // + row * 32
 
-    // newest_first: workgroup s takes tiles n_tiles - 1 - s, n_tiles - 1 - s - S, ... - every workgroup starts in the part of
-    // dy its producer (conv1_2's data gradient, which ends right in front of this launch) wrote LAST, the part that may still
-    // sit in the memory-side cache, and all of them work their way back to the oldest part together.  (With a contiguous
-    // range per workgroup the launch reads all of dy at once, most of it long evicted.)  The loop below counts tile - t_begin.
-    const int S_wg = gridDim.x;
-    const int t_begin = a.newest_first ? 0 : split * a.tiles_per_split;
-    const int t_end = a.newest_first ? (a.n_tiles - split + S_wg - 1) / S_wg : min(t_begin + a.tiles_per_split, a.n_tiles);
-    int lt_lin = a.newest_first ? a.n_tiles - 1 - split : t_begin;
+    // newest_first = G > 0: the tiles are taken in chunks of G consecutive ones (neighbours in a tile row: they share the
+    // 128-byte lines of the fp32 frame rows and their halo columns), workgroup s takes chunks n_chunks - 1 - s, - S, ... -
+    // every workgroup starts in the part of dy its producer (conv1_2's data gradient, which ends right in front of this
+    // launch) wrote LAST, the part that may still sit in the memory-side cache, and all of them work their way back to the
+    // oldest part together.  (With a contiguous range per workgroup the launch reads all of dy at once, most of it long
+    // evicted.)  The loop below counts tile - t_begin.
+    const int S_wg = gridDim.x, G_ch = a.newest_first;
+    const int n_chunks = G_ch ? (a.n_tiles + G_ch - 1) / G_ch : 0;
+    const int my_chunks = (G_ch && split < n_chunks) ? (n_chunks - split + S_wg - 1) / S_wg : 0;
+    const int t_begin = G_ch ? 0 : split * a.tiles_per_split;
+    const int t_end = G_ch ? my_chunks * G_ch - ((my_chunks && split == 0) ? n_chunks * G_ch - a.n_tiles : 0)
+                           : min(t_begin + a.tiles_per_split, a.n_tiles);
+    int lt_chunk = n_chunks - 1 - split, lt_j = 0;
+    int lt_lin = G_ch ? max(lt_chunk, 0) * G_ch : t_begin;
     int lt_x = lt_lin % a.tiles_x, lt_y = (lt_lin / a.tiles_x) % a.tiles_y, lt_n = lt_lin / (a.tiles_x * a.tiles_y);
 
     uint4 py0, py1, py2, py3;
@@ -125,8 +131,13 @@ __global__ __launch_bounds__(256) void k_wgrad_first(const FirstArgs a) {
         const float *fbase_ = a.frame + (int64_t)lt_n * 3 * H * W;                                        \
         FOSVOS_F_LDY(0) FOSVOS_F_LDY(1) FOSVOS_F_LDY(2) FOSVOS_F_LDY(3)                                   \
         FOSVOS_F_LDF(0) FOSVOS_F_LDF(1) FOSVOS_F_LDF(2)                                                   \
-        if (a.newest_first) {                                                                             \
-            lt_lin = max(lt_lin - S_wg, 0);                                                               \
+        if (G_ch) {                                                                                       \
+            ++lt_lin;                                                                                     \
+            if (++lt_j == G_ch || lt_lin >= a.n_tiles) {                                                  \
+                lt_chunk -= S_wg;                                                                         \
+                lt_lin = max(lt_chunk, 0) * G_ch;                                                         \
+                lt_j = 0;                                                                                 \
+            }                                                                                             \
             lt_x = lt_lin % a.tiles_x;                                                                    \
             lt_y = (lt_lin / a.tiles_x) % a.tiles_y;                                                      \
             lt_n = lt_lin / (a.tiles_x * a.tiles_y);                                                      \
@@ -269,7 +280,7 @@ int fosvos::first_wgrad_impl(const float *frame, const uint16_t *dy, float *dw, 
     a.bias_part = db ? reinterpret_cast<float *>(ws + p.slab_bytes) : nullptr;
     a.N = N; a.H = H; a.W = W;
     a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_tiles = p.n_tiles; a.tiles_per_split = p.tps;
-    a.newest_first = lab_env_int("FOSVOS_WGRAD_FIRST_ORDER", 1);  // lab switch: 0 = contiguous ranges
+    a.newest_first = lab_env_int("FOSVOS_WGRAD_FIRST_ORDER", 4);  // lab switch: 0 = contiguous ranges, G = chunk size
     FOSVOS_PROF("k_wgrad_first", st, 2.0 * N * H * W * 27.0 * CO);
     hipLaunchKernelGGL(k_wgrad_first, dim3((unsigned)p.S), dim3(256), LDS_BYTES, st, a);
     FOSVOS_LAUNCH_CHECK();
