@@ -395,6 +395,10 @@ class ArenaPool:
         # weight-gradient kernels on the auxiliary stream may still read
         self._pending: List[Tuple[int, int, int, torch.Tensor, Optional[torch.Tensor]]] = []
         self._home: Dict[int, Tuple[int, int, int, int]] = {}  # arena address -> the key it was allocated for
+        # a loop that batches up to this many frames of one size per pass (train_online: its group size) says so: a NEW arena
+        # is then sized for every batch from the pass's own up to this one, so that a frame size is allocated once - not
+        # again (hundreds of MB, milliseconds, in the middle of a cycle) the first time a larger group of it comes along
+        self.reserve_frames = 0
 
     def aux_stream(self, device_index: int) -> int:
         """Handle of the auxiliary HIP stream the backward pass issues its weight-gradient kernels on
@@ -427,8 +431,11 @@ class ArenaPool:
             # (an arena's size is not monotonic in N: fewer frames can mean more K splits and a larger workspace)
             if lst and h2 == h and w2 == w and d2 == dev and n2 > n and lst[-1].numel() >= nbytes + 256:
                 return lst.pop()
+        n_top = max(n, int(self.reserve_frames))
+        for m in range(n + 1, n_top + 1):
+            nbytes = max(nbytes, lib().fosvos_vgg_arena_bytes(m, h, w))
         arena = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
-        self._home[arena.data_ptr()] = key
+        self._home[arena.data_ptr()] = (n_top, h, w, dev)
         return arena
 
     def hold(self, n: int, h: int, w: int, arena: torch.Tensor, frame: Optional[torch.Tensor] = None) -> None:

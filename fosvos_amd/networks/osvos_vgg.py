@@ -126,6 +126,16 @@ class OSVOS_VGG(nn.Module):
         return bool(engine.USE_NATIVE_LOOP)
 
     @property
+    def reserve_arena_frames(self):
+        return self._packs.arenas.reserve_frames
+
+    @reserve_arena_frames.setter
+    def reserve_arena_frames(self, value):
+        """The largest batch of one frame size the caller's loop will pass: activation arenas allocated from now on are
+        sized for every batch up to it (engine.ArenaPool.reserve_frames), one allocation per frame size."""
+        self._packs.arenas.reserve_frames = max(0, int(value))
+
+    @property
     def overwrite_grads(self):
         return getattr(self._packs, "overwrite_grads", False)
 

@@ -443,6 +443,8 @@ def _train(net_provider: NetworkProvider, dataloader, optimizer: optim.SGD, summ
     n_iters = 0
     max_group = _max_group()
     max_window = max(max_group, _group_window())
+    if hasattr(net, 'reserve_arena_frames'):
+        net.reserve_arena_frames = min(max_group, avg_grad_every_n)  # (a pass never holds more frames than a cycle)
     window = []  # pending (epoch, minibatch index, minibatch, last of its epoch) tuples, all of one accumulation cycle
     for epoch in range(start_epoch, n_epochs):
         n_mb = len(dataloader)

@@ -758,6 +758,17 @@ def test_arena_pool_reuses_larger_free_arenas():
         assert got.data_ptr() != big.data_ptr() and got.numel() >= need3
     other = pool.take(3, 32, 56, dev)                      # another frame size: its own arena
     assert other.data_ptr() != big.data_ptr()
+    # reserve_frames (what train_online sets to its group size): a new arena fits every batch up to it, so the first pass of
+    # a frame size - whatever its group - is that size's only allocation
+    pool2 = engine.ArenaPool()
+    pool2.reserve_frames = 5
+    first = pool2.take(2, 40, 70, dev)
+    assert first.numel() >= 256 + max(lib().fosvos_vgg_arena_bytes(m, 40, 70) for m in range(2, 6))
+    pool2.give(2, 40, 70, first)
+    for m in (5, 1, 3):
+        got = pool2.take(m, 40, 70, dev)
+        assert got.data_ptr() == first.data_ptr(), m
+        pool2.give(m, 40, 70, got)
 
 
 def test_native_loop_equals_per_op_engine():
